@@ -1,0 +1,91 @@
+"""Build biseqt_amd/pwlib/pwlib.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m biseqt_amd.csrc.build [--force]
+
+One object per (score type, diagonals-per-lane) fill translation unit plus the traceback unit and the
+host API, compiled in parallel, linked into one shared object that exports the four drop-in functions
+of include/pwlib.h and the batch API of include/pw_batch.h.  The header is copied next to the library
+(biseqt_amd/pwlib/pwlib.h) the way the reference keeps biseqt/pwlib/pwlib.{h,so} side by side.
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT_DIR = os.path.join(os.path.dirname(HERE), 'pwlib')
+OBJ_DIR = os.path.join(HERE, '_build')
+SO = os.path.join(OUT_DIR, 'pwlib.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+# -ffp-contract=off: the f64 path must add exactly as the reference does, (H + ge) + go, no FMA
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
+          '-Wno-unused-function']
+BKS = (2, 4, 8, 16, 32)
+TYPES = (('i32', 'int32_t'), ('f64', 'double'))
+HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
+
+
+def _jobs():
+    jobs = []
+    for tn, t in TYPES:
+        for bk in BKS:
+            obj = os.path.join(OBJ_DIR, 'pw_fill_%s_bk%d.o' % (tn, bk))
+            cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
+                                      os.path.join(HERE, 'pw_fill_tu.hip'), '-o', obj]
+            jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tu.hip')]))
+    obj = os.path.join(OBJ_DIR, 'pw_trace.o')
+    jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_trace.hip'), '-o', obj],
+                 [os.path.join(HERE, 'pw_trace.hip')]))
+    obj = os.path.join(OBJ_DIR, 'pwlib_api.o')
+    jobs.append((obj, [HIPCC] + COMMON + ['-x', 'hip', '-c', os.path.join(HERE, 'pwlib_api.cpp'), '-o', obj],
+                 [os.path.join(HERE, 'pwlib_api.cpp'), os.path.join(ROOT, 'include', 'pwlib.h'),
+                  os.path.join(ROOT, 'include', 'pw_batch.h')]))
+    return jobs
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    jobs = _jobs()
+    todo = [(o, c) for (o, c, deps) in jobs if force or _stale(o, deps + hdrs + [os.path.abspath(__file__)])]
+
+    def run(job):
+        obj, cmd = job
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        return obj, r.returncode, r.stdout
+
+    workers = max(1, min(len(todo), (os.cpu_count() or 4)))
+    if todo:
+        if verbose:
+            print('[build] compiling %d objects for %s with %d workers' % (len(todo), ARCH, workers))
+        with concurrent.futures.ThreadPoolExecutor(workers) as ex:
+            for obj, rc, out in ex.map(run, todo):
+                if rc != 0:
+                    raise RuntimeError('hipcc failed for %s:\n%s' % (obj, out))
+                if verbose and out.strip():
+                    print(out)
+    objs = [o for (o, _, _) in jobs]
+    if force or todo or _stale(SO, objs):
+        cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', SO]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n' + r.stdout)
+        if verbose:
+            print('[build] linked', SO)
+    shutil.copyfile(os.path.join(ROOT, 'include', 'pwlib.h'), os.path.join(OUT_DIR, 'pwlib.h'))
+    return SO
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

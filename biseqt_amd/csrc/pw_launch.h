@@ -1,0 +1,25 @@
+// pw_launch.h -- host-visible launchers of the gfx950 kernels in pw_kernels.hip.
+#ifndef PW_LAUNCH_H
+#define PW_LAUNCH_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "pw_types.h"
+
+namespace pw {
+
+// Fill-kernel variants (template switches of WaveFill, pw_wave.h).
+enum { VAR_FAST_ANY_TRACK = 0,  // begin anywhere + per-diagonal best: LOCAL, B_LOCAL (END_ANCHORED rides along)
+       VAR_FAST_TRACK = 1,      // begin at origin/edges + per-diagonal best: START_ANCHORED
+       VAR_FAST = 2,            // begin at origin/edges, end on the table edge: GLOBAL, *OVERLAP, B_GLOBAL, B_OVERLAP
+       VAR_GENERIC = 3 };       // substitution matrix / go > 0 / score-plane dump: everything at run time
+
+static const int kSupportedBK[] = {2, 4, 8, 16, 32};
+static const int kNumSupportedBK = 5;
+
+hipError_t launch_fill(const FillParams<int32_t>& a, int variant, int bk, int nblocks, hipStream_t st);
+hipError_t launch_fill(const FillParams<double>& a, int variant, int bk, int nblocks, hipStream_t st);
+hipError_t launch_trace(const TraceParams& p, hipStream_t st);
+
+}  // namespace pw
+#endif

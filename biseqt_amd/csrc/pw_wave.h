@@ -1,0 +1,422 @@
+// pw_wave.h -- the per-lane program of the banded anti-diagonal wavefront fill ("K1") and of the
+// traceback walker ("K4").
+//
+// What it computes: the reference's dptable_solve (biseqt/pwlib/pw.c:47-114) with its move
+// generators (_pw_internals.c:161-299) and end-cell search (:303-414), restated as
+// (H, 4-bit ordered tie mask) per cell, and dptable_traceback (pw.c:116-151)
+// restated over the tie masks.
+//
+// How it is laid out on a 64-lane CDNA wavefront (one wavefront per sequence pair):
+//   * band coordinates: diagonal d = x - y, anti-diagonal s = x + y.  Lane l owns the BK (even)
+//     consecutive diagonals dd = l*BK .. l*BK+BK-1 (dd = d - dmin); their running state
+//     (H, the gap offers U/L, mask accumulator, best-so-far) lives in registers.
+//   * a step advances one anti-diagonal; slot j holds a cell on the steps t == j (mod 2), so each
+//     step a lane updates R = BK/2 independent cells in place: the diagonal predecessor is the slot's
+//     own previous value, the up/left predecessors are the neighbouring slots' values from the
+//     previous step.  Only the two block-edge values cross lanes, one DPP wave shift per step.
+//   * the sequences stream through the lanes systolically: origin letters move towards lower lanes,
+//     mutant letters towards higher lanes, one DPP shift per step; the edge lanes are fed from the
+//     sequence arena with wave-uniform loads.
+//   * every 16 steps each slot has accumulated 8 tie masks = one dword; the wave stores them with
+//     16-byte-per-lane, 1 KiB-contiguous stores (layout: pw_types.h, mask_word_index).
+//
+// The file is written against a tiny platform policy P (lane id, wave shifts, shuffles, barrier) so
+// that the very same lane program is compiled by hipcc into the gfx950 kernels (pw_kernels.hip) and
+// by g++ into a 64-fiber lockstep emulator used only by the CPU tests (tests/emu).  PW_FN is the
+// function qualifier each side supplies.
+#ifndef PW_WAVE_H
+#define PW_WAVE_H
+
+#ifndef PW_FN
+#error "PW_FN must be defined by the includer"
+#endif
+
+#include "pw_types.h"
+
+namespace pw {
+
+template <typename T> struct ScoreTraits;
+template <> struct ScoreTraits<int32_t> {
+  static constexpr bool is_int = true;
+  // "no such predecessor".  Real scores are kept within +-2^27 by the host planner, so a sentinel
+  // (even after a few thousand additions of small scores) never reaches a real score, and the sum of
+  // two sentinels still fits an int32.
+  PW_FN static int32_t neg() { return -(1 << 28); }
+  PW_FN static int32_t zero_blk() { return 0; }
+};
+template <> struct ScoreTraits<double> {
+  static constexpr bool is_int = false;
+  PW_FN static double neg() { return -1.0e300; }
+  PW_FN static double zero_blk() { return -0.0; }   // x + (-0.0) == x bit for bit, also for x = +-0
+};
+
+// ---- cross-lane moves for any score type, built on the platform's 32-bit wave shifts -----------
+template <class P> PW_FN int32_t xshr1(int32_t v, int32_t old) { return P::shr1(v, old); }
+template <class P> PW_FN int32_t xshl1(int32_t v, int32_t old) { return P::shl1(v, old); }
+template <class P> PW_FN uint32_t xshr1(uint32_t v, uint32_t old) { return (uint32_t)P::shr1((int32_t)v, (int32_t)old); }
+template <class P> PW_FN uint32_t xshl1(uint32_t v, uint32_t old) { return (uint32_t)P::shl1((int32_t)v, (int32_t)old); }
+union D2I { double d; int32_t i[2]; };
+template <class P> PW_FN double xshr1(double v, double old) {
+  D2I a, o, r; a.d = v; o.d = old;
+  r.i[0] = P::shr1(a.i[0], o.i[0]); r.i[1] = P::shr1(a.i[1], o.i[1]);
+  return r.d;
+}
+template <class P> PW_FN double xshl1(double v, double old) {
+  D2I a, o, r; a.d = v; o.d = old;
+  r.i[0] = P::shl1(a.i[0], o.i[0]); r.i[1] = P::shl1(a.i[1], o.i[1]);
+  return r.d;
+}
+template <class P> PW_FN int32_t xshfl_xor(int32_t v, int m) { return P::shfl_xor(v, m); }
+template <class P> PW_FN double xshfl_xor(double v, int m) {
+  D2I a, r; a.d = v;
+  r.i[0] = P::shfl_xor(a.i[0], m); r.i[1] = P::shfl_xor(a.i[1], m);
+  return r.d;
+}
+template <class P> PW_FN uint64_t xshfl_xor(uint64_t v, int m) {
+  uint32_t lo = (uint32_t)P::shfl_xor((int32_t)(uint32_t)v, m);
+  uint32_t hi = (uint32_t)P::shfl_xor((int32_t)(uint32_t)(v >> 32), m);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+PW_FN int32_t pw_clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// =================================================================================================
+// K1: fill one pair.  Template switches:
+//   BK       diagonals per lane (even); the wave covers 64*BK diagonals
+//   BANY     an alignment may begin anywhere (LOCAL, END_ANCHORED, B_LOCAL)         [fast kernels]
+//   TRACK    keep the first best cell of every diagonal (needed by the *LOCAL end rules)
+//   GENERIC  everything at run time: substitution matrix lookup, begin rule, sign of the gap-open
+//            score, optional dump of the score plane.  (BANY/TRACK are ignored: TRACK is on.)
+// =================================================================================================
+template <class P, typename T, int BK, bool BANY, bool TRACK_, bool GENERIC>
+struct WaveFill {
+  static constexpr int R = BK / 2;
+  static constexpr bool TRACK = TRACK_ || GENERIC;
+  using Tr = ScoreTraits<T>;
+
+  // ---- uniform (per pair) ----
+  const FillParams<T>& a;
+  const PairDesc& pd;
+  const T* sub_tab;           // substitution table (LDS on the device) for GENERIC
+  const uint8_t* oseq;
+  const uint8_t* mseq;
+  int X, Y, ndiag, olast, mlast;
+
+  // ---- per lane ----
+  int lane;
+  int njl;                    // slot j is inside the band iff j < njl
+  int xbase, ybase;           // (x, y) of slot 0 on the even step of the current iteration
+  T H[BK], U[BK], L[BK], blkL[BK], best[BK];
+  int32_t bestT[BK];
+  uint32_t m[BK];
+  uint32_t ow[R], mw[R];
+
+  PW_FN WaveFill(const FillParams<T>& a_, const PairDesc& pd_, const T* sub_tab_)
+      : a(a_), pd(pd_), sub_tab(sub_tab_) {}
+
+  PW_FN T subst(uint32_t oc, uint32_t mc) const {
+    if (GENERIC) return sub_tab[oc * (uint32_t)a.L + mc];
+    return oc == mc ? a.match : a.mismatch;
+  }
+
+  // One cell of slot J on step t (lane-local coordinates x, y).
+  template <bool RAMP, int J>
+  PW_FN void cell(T up, T left, uint32_t oc, uint32_t mc, int x, int y, int t) {
+    const T hD = up, hI = left;
+    const T hM = H[J] + subst(oc, mc);
+    bool active = true;
+    bool ball;
+    if (RAMP) {
+      active = (J < njl) && ((uint32_t)x <= (uint32_t)X) && ((uint32_t)y <= (uint32_t)Y);
+      const int brule = GENERIC ? a.brule : (BANY ? (int)BRULE_ANY : a.brule);
+      const bool edge = (x == 0) || (y == 0);
+      const bool orig = (x == 0) && (y == 0);
+      ball = (brule == BRULE_ANY) || (edge && (brule == BRULE_EDGE || orig));
+    } else {
+      ball = GENERIC ? (a.brule == BRULE_ANY) : BANY;   // no first cells in the steady phase
+    }
+    // maximum in the reference's candidate order B, D, I, M, later candidates replace only when
+    // strictly greater (pw.c:92-103)
+    T Hn;
+    if (Tr::is_int) {
+      Hn = hD > hI ? hD : hI;
+      Hn = hM > Hn ? hM : Hn;
+      const T b0 = ball ? T(0) : Tr::neg();
+      Hn = b0 > Hn ? b0 : Hn;
+    } else {
+      Hn = ball ? T(0) : hD;
+      if (ball) Hn = hD > Hn ? hD : Hn;
+      Hn = hI > Hn ? hI : Hn;
+      Hn = hM > Hn ? hM : Hn;
+    }
+    const bool bB = ball && (Hn == T(0));
+    const bool bD = (hD == Hn), bI = (hI == Hn), bM = (hM == Hn);
+    // what this cell offers downwards (as a D predecessor) and rightwards (as an I predecessor):
+    // _alnchoice_ID scans the kept choices, (H + ge) [+ go when the kept op differs], first strict max
+    // (_pw_internals.c:268-278).  All kept choices share H, so only "is the same op kept" matters.
+    const T A = Hn + a.ge;
+    T Un, Ln;
+    if (!GENERIC) {                 // go <= 0 guaranteed by the planner
+      if (Tr::is_int) {
+        const T gego = a.ge + a.go;
+        Un = Hn + (bD ? a.ge : gego);
+        Ln = Hn + (bI ? a.ge : gego) + blkL[J];
+      } else {
+        const T Bv = A + a.go;
+        Un = bD ? A : Bv;
+        Ln = (bI ? A : Bv) + blkL[J];
+      }
+    } else {
+      const T Bv = A + a.go;
+      const T hi = A > Bv ? A : Bv;
+      const bool oD = bB || bI || bM, oI = bB || bD || bM;   // some other op kept as well
+      Un = bD ? (oD ? hi : A) : Bv;
+      Ln = (bI ? (oI ? hi : A) : Bv) + blkL[J];
+    }
+    const uint32_t nib = (bB ? (uint32_t)MB : 0u) | (bD ? (uint32_t)MD : 0u) |
+                         (bI ? (uint32_t)MI : 0u) | (bM ? (uint32_t)MM : 0u);
+    if (RAMP) {
+      m[J] = (m[J] << 4) | (active ? nib : 0u);
+      H[J] = active ? Hn : H[J];
+      U[J] = active ? Un : U[J];
+      L[J] = active ? Ln : L[J];
+      if (TRACK) {
+        const bool upd = active && (Hn > best[J]);
+        best[J] = upd ? Hn : best[J];
+        bestT[J] = upd ? t : bestT[J];
+      }
+    } else {
+      m[J] = (m[J] << 4) | nib;
+      H[J] = Hn; U[J] = Un; L[J] = Ln;
+      if (TRACK) {
+        const bool upd = Hn > best[J];
+        best[J] = upd ? Hn : best[J];
+        bestT[J] = upd ? t : bestT[J];
+      }
+    }
+    if (GENERIC) {
+      if (a.hdump != nullptr && active && (RAMP || J < njl)) {
+        const int aa = x < y ? x : y;
+        a.hdump[pd.h_off + (uint64_t)(lane * BK + J) * (uint64_t)pd.h_pitch + (uint64_t)aa] = Hn;
+      }
+    }
+  }
+
+  // compile-time loops over the slots of one parity
+  template <bool RAMP, int I> struct EvenLoop {
+    PW_FN static void run(WaveFill& w, T uin, int t) {
+      w.template cell<RAMP, 2 * I>(I == 0 ? uin : w.U[(2 * I - 1 + BK) % BK], w.L[2 * I + 1], w.ow[I], w.mw[I],
+                                   w.xbase + I, w.ybase - I, t);
+      EvenLoop<RAMP, I + 1>::run(w, uin, t);
+    }
+  };
+  template <bool RAMP> struct EvenLoop<RAMP, R> { PW_FN static void run(WaveFill&, T, int) {} };
+  template <bool RAMP, int I> struct OddLoop {
+    PW_FN static void run(WaveFill& w, T lin, int t) {
+      w.template cell<RAMP, 2 * I + 1>(w.U[2 * I], I == R - 1 ? lin : w.L[(2 * I + 2) % BK], w.ow[I], w.mw[I],
+                                       w.xbase + I + 1, w.ybase - I, t);
+      OddLoop<RAMP, I + 1>::run(w, lin, t);
+    }
+  };
+  template <bool RAMP> struct OddLoop<RAMP, R> { PW_FN static void run(WaveFill&, T, int) {} };
+
+  // One iteration = the even step 2*it and the odd step 2*it + 1.
+  template <bool RAMP>
+  PW_FN void iteration(int it) {
+    // even step: slot 0 takes its "up" offer from the previous lane's last slot
+    const T uin = xshr1<P>(U[BK - 1], Tr::neg());
+    EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
+    // the origin window moves on by one letter: lane l takes lane l+1's lowest letter, the last lane
+    // is fed from the arena
+    {
+      const int oi = xfeed_o + it;
+      const uint32_t feed = oseq[pw_clampi(oi, 0, olast)];
+      const uint32_t oin = xshl1<P>(ow[0], feed);
+#pragma unroll
+      for (int i = 0; i + 1 < R; i++) ow[i] = ow[i + 1];
+      ow[R - 1] = oin;
+    }
+    // odd step: the last slot takes its "left" offer from the next lane's slot 0
+    const T lin = xshl1<P>(L[0], Tr::neg());
+    OddLoop<RAMP, 0>::run(*this, lin, 2 * it + 1);
+    // the mutant window moves on: lane l takes lane l-1's highest letter, lane 0 is fed from the arena
+    {
+      const int mi = yfeed_m + it;
+      const uint32_t feed = mseq[pw_clampi(mi, 0, mlast)];
+      const uint32_t min_ = xshr1<P>(mw[R - 1], feed);
+#pragma unroll
+      for (int i = R - 1; i > 0; i--) mw[i] = mw[i - 1];
+      mw[0] = min_;
+    }
+    xbase++; ybase++;
+  }
+
+  int xfeed_o, yfeed_m;       // uniform: arena index the edge lanes are fed from at iteration 0
+
+  // A block = 16 steps = 8 iterations = one mask dword per slot.  The steady body is fully unrolled (the
+  // letter-window shifts become register renames); the predicated ramp body runs only at the two ends
+  // of a pair and is kept rolled to bound code size and scalar-register pressure.
+  template <bool RAMP>
+  PW_FN void block(int b) {
+    if (RAMP) {
+#pragma unroll 1
+      for (int k = 0; k < 8; k++) iteration<true>(8 * b + k);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) iteration<false>(8 * b + k);
+    }
+  }
+
+  PW_FN void store_masks(int b) {
+    if (lane * BK < ndiag) {
+      uint32_t* dst = a.masks + pd.mask_off;
+#pragma unroll
+      for (int j = 0; j < BK; j++) dst[mask_word_index(BK, b, lane, j)] = m[j];
+    }
+  }
+
+  PW_FN void run() {
+    lane = P::lane();
+    X = pd.X; Y = pd.Y; ndiag = pd.ndiag;
+    oseq = a.arena + pd.o_off; mseq = a.arena + pd.m_off;
+    olast = X > 0 ? X - 1 : 0; mlast = Y > 0 ? Y - 1 : 0;
+    njl = ndiag - lane * BK;
+    // s0 == dmin (mod 2): e, f are exact
+    const int e = (pd.s0 + pd.dmin) >> 1;       // x of diagonal dd = 0 on step t = 0
+    const int f = (pd.s0 - pd.dmin) >> 1;       // y of diagonal dd = 0 on step t = 0
+    xbase = e + lane * R;
+    ybase = f - lane * R;
+    xfeed_o = e + 64 * R - 1;                   // letter o[xbase + R - 1] of a virtual lane 64
+    yfeed_m = f;                                // letter m[ybase] of lane 0
+#pragma unroll
+    for (int j = 0; j < BK; j++) {
+      H[j] = Tr::neg(); U[j] = Tr::neg(); L[j] = Tr::neg();
+      best[j] = Tr::neg(); bestT[j] = 0; m[j] = 0;
+      // the first diagonal above the band must never offer an insertion into the band
+      blkL[j] = (lane * BK + j == ndiag) ? Tr::neg() : Tr::zero_blk();
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+      ow[i] = oseq[pw_clampi(xbase + i - 1, 0, olast)];
+      mw[i] = mseq[pw_clampi(ybase - i - 1, 0, mlast)];
+    }
+    for (int b = 0; b < pd.nblocks; b++) {
+      if (b >= pd.steady_b0 && b < pd.steady_b1) block<false>(b);
+      else block<true>(b);
+      store_masks(b);
+    }
+    finish();
+  }
+
+  // ---- end-cell search: reduce (score desc, scan rank asc) over the in-band diagonals ----------
+  PW_FN void finish() {
+    const int endrule = a.endrule;
+    T cs = Tr::neg(); uint64_t ck = ~(uint64_t)0; int cx = -1, cy = -1; bool have = false;
+#pragma unroll
+    for (int j = 0; j < BK; j++) {
+      const int dd = lane * BK + j;
+      const int d = pd.dmin + dd;
+      const bool inband = dd < ndiag;
+      // last cell of diagonal d
+      const bool ends_right = d < X - Y;           // ends on the right column y = Y, else bottom row x = X
+      const int lx = ends_right ? d + Y : X, ly = ends_right ? Y : X - d;
+      T s; uint64_t k; int x, y; bool ok = inband;
+      if (endrule == END_CORNER) {
+        ok = ok && (d == X - Y); s = H[j]; k = 0; x = X; y = Y;
+      } else if (endrule == END_STD_OVERLAP) {
+        // row-major over last column (x < X) then last row: rank x for (x, Y), X + y for (X, y)
+        s = H[j]; x = lx; y = ly; k = ends_right ? (uint64_t)(uint32_t)lx : (uint64_t)(uint32_t)(X + ly);
+      } else if (endrule == END_BANDED_OVERLAP) {
+        s = H[j]; x = lx; y = ly; k = (uint64_t)(uint32_t)dd;
+      } else {
+        // first best cell of the diagonal: step bestT -> index along the diagonal
+        const int tfirst = (d < 0 ? -d : d) - pd.s0;
+        const int aa = (bestT[j] - tfirst) >> 1;
+        s = best[j]; x = aa + (d > 0 ? d : 0); y = aa - (d < 0 ? d : 0);
+        if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
+        else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
+      }
+      const bool better = ok && (!have || s > cs || (s == cs && k < ck));
+      if (better) { cs = s; ck = k; cx = x; cy = y; have = true; }
+    }
+    // butterfly over the 64 lanes
+    int hv = have ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const T os = xshfl_xor<P>(cs, off);
+      const uint64_t ok_ = xshfl_xor<P>(ck, off);
+      const int ox = P::shfl_xor(cx, off), oy = P::shfl_xor(cy, off), oh = P::shfl_xor(hv, off);
+      const bool take = oh && (!hv || os > cs || (os == cs && ok_ < ck));
+      if (take) { cs = os; ck = ok_; cx = ox; cy = oy; hv = 1; }
+    }
+    if (lane == 0) {
+      Result r;
+      r.score = (double)cs;
+      // table coordinates as dptable_solve returns them (_cellpos_from_xy, _pw_internals.c:87-98)
+      r.opt_i = a.banded ? cx - cy - pd.dmin : cx;
+      r.opt_j = a.banded ? (cx < cy ? cx : cy) : cy;
+      r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;
+      // LOCAL / START_ANCHORED start from the score of cell (0,0), i.e. 0 (_pw_internals.c:342)
+      if (!hv || (endrule == END_STD_LOCAL && !(cs > T(0)))) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; }
+      a.results[pair_slot] = r;
+    }
+  }
+  int pair_slot;
+};
+
+// =================================================================================================
+// K4: traceback of one pair by one lane, over the tie-mask plane.
+// Predecessor rule after a gap op g (pinned by oracle `maskrule_ok`): go < 0 -> g if g is
+// kept in the predecessor else its first kept op; go == 0 -> first kept; go > 0 -> first kept op
+// other than g, else g.  After M/S: first kept (_pw_internals.c:235).
+// =================================================================================================
+PW_FN uint32_t pw_mask_at(const TraceParams& p, const PairDesc& pd, int x, int y) {
+  const int dd = x - y - pd.dmin;
+  const int t = x + y - pd.s0;
+  const int lane = dd / pd.bk, j = dd % pd.bk;
+  const uint32_t w = p.masks[pd.mask_off + mask_word_index(pd.bk, t >> 4, lane, j)];
+  return (w >> (4 * (7 - ((t & 15) >> 1)))) & 15u;
+}
+
+PW_FN int pw_first_op(uint32_t mask) {   // index of the lowest set bit: 0 B, 1 D, 2 I, 3 M
+  return (mask & 1u) ? 0 : (mask & 2u) ? 1 : (mask & 4u) ? 2 : 3;
+}
+
+PW_FN void trace_pair(const TraceParams& p, int pair) {
+  const PairDesc& pd = p.pairs[pair];
+  if (!pd.solvable) return;
+  Result r = p.results[pair];
+  const int ei = p.ends ? p.ends[2 * pair] : r.opt_i;
+  const int ej = p.ends ? p.ends[2 * pair + 1] : r.opt_j;
+  if (ei < 0 || ej < 0) { r.tx_len = 0; r.status = 0; p.results[pair] = r; return; }
+  int x = ei, y = ej;
+  if (p.banded) {                 // _xy_from_cellpos (_pw_internals.c:100-114)
+    const int d = ei + pd.dmin;
+    x = ej + (d > 0 ? d : 0); y = ej - (d > 0 ? 0 : d);
+  }
+  const uint8_t* oseq = p.arena + pd.o_off;
+  const uint8_t* mseq = p.arena + pd.m_off;
+  uint8_t* tx = p.transcripts + pd.tx_off;
+  int pos = pd.tx_cap;            // ops are written backwards, ending right-aligned in the slot
+  int nms = 0;
+  uint32_t mask = pw_mask_at(p, pd, x, y);
+  int op = pw_first_op(mask);     // choices[0] of the end cell (pw.c:123)
+  while (op != 0 && pos > 0) {
+    uint8_t ch;
+    if (op == 3) { ch = (oseq[x - 1] == mseq[y - 1]) ? 'M' : 'S'; nms++; x--; y--; }
+    else if (op == 1) { ch = 'D'; x--; }
+    else { ch = 'I'; y--; }
+    tx[--pos] = ch;
+    const uint32_t pm = pw_mask_at(p, pd, x, y);
+    if (op == 3 || p.gosign == 0) op = pw_first_op(pm);
+    else if (p.gosign < 0) op = (pm & (1u << op)) ? op : pw_first_op(pm);
+    else { const uint32_t others = pm & ~(1u << op); op = others ? pw_first_op(others) : op; }
+  }
+  r.origin_idx = x; r.mutant_idx = y;
+  r.tx_len = pd.tx_cap - pos;
+  r.status = ST_TRACED | (r.tx_len == 0 ? ST_EMPTY : 0) | ((x + y + nms <= 0) ? ST_PANICK : 0);
+  p.results[pair] = r;
+}
+
+}  // namespace pw
+#endif

@@ -1,0 +1,596 @@
+// pwlib_api.cpp -- host side of libpwlib (pwlib.so): the batch C ABI of include/pw_batch.h and, on
+// top of it, the four drop-in functions of include/pwlib.h (reference biseqt/pwlib/pw.c).
+//
+// Everything that computes runs in the gfx950 kernels of pw_device.h / pw_trace.hip; this file plans
+// (pw_plan.h), moves bytes and launches.  There is no CPU fallback: what the kernels do not support is
+// reported as an error.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/pw_batch.h"
+#include "pw_launch.h"
+#include "pw_plan.h"
+
+extern "C" {
+#include "../../include/pwlib.h"
+}
+
+static_assert(sizeof(pw::Result) == 32 && sizeof(pw_result) == 32, "result record must be 32 bytes");
+static_assert(sizeof(pw::PairDesc) == 96, "PairDesc layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) { g_err = msg; return -1; }
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+struct BkClass {
+  int bk = 0;
+  std::vector<int32_t> order;   // pair indices, largest table first
+  int32_t* d_order = nullptr;
+};
+
+}  // namespace
+
+struct pw_batch {
+  int device = 0;
+  int32_t n = 0;
+  uint32_t flags = 0;
+  int mode = 0, type = 0, L = 0;
+  double go = 0, ge = 0;
+  std::vector<double> subst;
+  bool simple = false, use_f64 = false;
+  int variant = 0, brule = 0, endrule = 0, gosign = 0;
+  std::vector<pw_pair> pairs;
+  std::vector<pw::Plan> plans;
+  std::vector<pw::PairDesc> descs;
+  std::vector<BkClass> classes;
+  int64_t cells = 0, alg_bytes = 0;
+  // device
+  uint8_t* d_arena = nullptr; uint64_t arena_bytes = 0;
+  pw::PairDesc* d_pairs = nullptr;
+  uint32_t* d_masks = nullptr; uint64_t mask_words = 0;
+  void* d_hdump = nullptr; uint64_t h_elems = 0;
+  pw::Result* d_results = nullptr;
+  uint8_t* d_tx = nullptr; uint64_t tx_bytes = 0;
+  void* d_subst = nullptr;
+  int32_t* d_ends = nullptr;
+  hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr, ev_tr0 = nullptr, ev_tr1 = nullptr;
+  bool fill_timed = false, trace_timed = false;
+};
+
+namespace {
+
+int batch_free_device(pw_batch* b) {
+  if (!b) return 0;
+  (void)hipSetDevice(b->device);
+  for (auto& c : b->classes) if (c.d_order) (void)hipFree(c.d_order);
+  if (b->d_arena) (void)hipFree(b->d_arena);
+  if (b->d_pairs) (void)hipFree(b->d_pairs);
+  if (b->d_masks) (void)hipFree(b->d_masks);
+  if (b->d_hdump) (void)hipFree(b->d_hdump);
+  if (b->d_results) (void)hipFree(b->d_results);
+  if (b->d_tx) (void)hipFree(b->d_tx);
+  if (b->d_subst) (void)hipFree(b->d_subst);
+  if (b->d_ends) (void)hipFree(b->d_ends);
+  if (b->ev_fill0) (void)hipEventDestroy(b->ev_fill0);
+  if (b->ev_fill1) (void)hipEventDestroy(b->ev_fill1);
+  if (b->ev_tr0) (void)hipEventDestroy(b->ev_tr0);
+  if (b->ev_tr1) (void)hipEventDestroy(b->ev_tr1);
+  return 0;
+}
+
+bool is_integral(double v) { return v == floor(v) && fabs(v) < 1e9; }
+
+int batch_build(pw_batch* b) {
+  // ---- scoring analysis ----
+  const int L = b->L;
+  bool integral = is_integral(b->go) && is_integral(b->ge);
+  double maxabs = std::max(fabs(b->go), std::max(fabs(b->ge), fabs(b->go + b->ge)));
+  b->simple = true;
+  const double mt = b->subst[0], mm = L > 1 ? b->subst[1] : b->subst[0];
+  for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) {
+    const double v = b->subst[(size_t)i * L + j];
+    if (!(v == v) || fabs(v) > 1e300) return fail("substitution scores must be finite");
+    integral = integral && is_integral(v);
+    maxabs = std::max(maxabs, fabs(v));
+    if (v != (i == j ? mt : mm)) b->simple = false;
+  }
+  pw::plan_rules(b->mode, b->type, &b->brule, &b->endrule);
+  b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
+  // ---- per-pair plans ----
+  int64_t maxspan = 0;
+  b->plans.resize(b->n); b->descs.resize(b->n);
+  uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
+  for (int32_t k = 0; k < b->n; k++) {
+    const pw_pair& p = b->pairs[k];
+    if (p.origin_len < 0 || p.mutant_len < 0) return fail("negative sequence length");
+    if (p.origin_off + (uint64_t)p.origin_len > b->arena_bytes || p.mutant_off + (uint64_t)p.mutant_len > b->arena_bytes)
+      return fail("pair frame outside the arena");
+    if ((int64_t)p.origin_len + p.mutant_len > (1 << 30)) return fail("sequences too long");
+    pw::Plan pl = pw::plan_problem(b->mode, b->type, p.origin_len, p.mutant_len, p.dmin, p.dmax);
+    b->plans[k] = pl;
+    pw::PairDesc d;
+    memset(&d, 0, sizeof d);
+    d.o_off = p.origin_off; d.m_off = p.mutant_off;
+    d.X = p.origin_len; d.Y = p.mutant_len;
+    d.solvable = (pl.rc == 0 && pl.ndiag > 0) ? 1 : 0;
+    d.tx_off = tx_bytes;
+    d.tx_cap = p.origin_len + p.mutant_len + 1;
+    tx_bytes += ((uint64_t)d.tx_cap + 15) / 16 * 16;
+    if (d.solvable) {
+      const int bk = pw::plan_pick_bk(pl.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
+      if (bk == 0) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); tiled kernel not built yet",
+                 (int)k, pl.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
+        return fail(msg);
+      }
+      d.dmin = pl.dmin; d.ndiag = pl.ndiag; d.s0 = pl.s0; d.nblocks = pl.nblocks;
+      d.steady_b0 = pl.steady_b0; d.steady_b1 = pl.steady_b1;
+      d.bk = bk;
+      d.mask_off = mask_words;
+      mask_words += (uint64_t)pl.nblocks * 64 * bk;
+      d.h_pitch = std::min(p.origin_len, p.mutant_len) + 1;
+      d.h_off = h_elems;
+      if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)pl.ndiag * d.h_pitch;
+      b->cells += pl.cells;
+      b->alg_bytes += pl.cells / 2 + p.origin_len + p.mutant_len + 32;
+      maxspan = std::max<int64_t>(maxspan, (int64_t)p.origin_len + p.mutant_len + 2);
+      size_t ci = 0;
+      for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk) break;
+      if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; }
+      b->classes[ci].order.push_back(k);
+    }
+    b->descs[k] = d;
+  }
+  // int32 is exact iff every score is an integer and no partial sum can leave +-2^27 (pw_wave.h)
+  b->use_f64 = (b->flags & PW_FLAG_FORCE_F64) || !integral || (double)maxspan * maxabs >= (double)(1 << 27);
+  const bool bany = b->brule == pw::BRULE_ANY;
+  const bool track = b->endrule == pw::END_STD_LOCAL || b->endrule == pw::END_BANDED_LOCAL;
+  if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || !b->simple || b->go > 0) b->variant = pw::VAR_GENERIC;
+  else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
+  else if (track) b->variant = pw::VAR_FAST_TRACK;
+  else b->variant = pw::VAR_FAST;
+  for (auto& c : b->classes)
+    std::stable_sort(c.order.begin(), c.order.end(), [&](int32_t x, int32_t y) {
+      return b->descs[x].nblocks > b->descs[y].nblocks;
+    });
+  // ---- device buffers ----
+  HIP_TRY(hipSetDevice(b->device));
+  b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
+  HIP_TRY(hipMalloc((void**)&b->d_arena, std::max<uint64_t>(b->arena_bytes, 16)));
+  HIP_TRY(hipMalloc((void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1)));
+  HIP_TRY(hipMalloc((void**)&b->d_masks, 4 * std::max<uint64_t>(mask_words, 4)));
+  HIP_TRY(hipMalloc((void**)&b->d_results, sizeof(pw::Result) * std::max<int32_t>(b->n, 1)));
+  HIP_TRY(hipMalloc((void**)&b->d_tx, std::max<uint64_t>(tx_bytes, 16)));
+  const size_t esz = b->use_f64 ? 8 : 4;
+  if (h_elems) HIP_TRY(hipMalloc(&b->d_hdump, esz * h_elems));
+  HIP_TRY(hipMalloc(&b->d_subst, esz * (size_t)L * L));
+  if (b->use_f64) {
+    HIP_TRY(hipMemcpy(b->d_subst, b->subst.data(), 8 * (size_t)L * L, hipMemcpyHostToDevice));
+  } else {
+    std::vector<int32_t> si((size_t)L * L);
+    for (size_t i = 0; i < si.size(); i++) si[i] = (int32_t)b->subst[i];
+    HIP_TRY(hipMemcpy(b->d_subst, si.data(), 4 * si.size(), hipMemcpyHostToDevice));
+  }
+  if (b->n) HIP_TRY(hipMemcpy(b->d_pairs, b->descs.data(), sizeof(pw::PairDesc) * b->n, hipMemcpyHostToDevice));
+  for (auto& c : b->classes) {
+    HIP_TRY(hipMalloc((void**)&c.d_order, 4 * c.order.size()));
+    HIP_TRY(hipMemcpy(c.d_order, c.order.data(), 4 * c.order.size(), hipMemcpyHostToDevice));
+  }
+  {  // records of pairs no kernel will touch
+    std::vector<pw::Result> init(std::max<int32_t>(b->n, 1));
+    for (auto& r : init) { r.score = 0; r.opt_i = r.opt_j = -1; r.origin_idx = r.mutant_idx = 0; r.tx_len = 0; r.status = 0; }
+    HIP_TRY(hipMemcpy(b->d_results, init.data(), sizeof(pw::Result) * init.size(), hipMemcpyHostToDevice));
+  }
+  if (b->flags & PW_FLAG_PROFILE) {
+    HIP_TRY(hipEventCreate(&b->ev_fill0)); HIP_TRY(hipEventCreate(&b->ev_fill1));
+    HIP_TRY(hipEventCreate(&b->ev_tr0)); HIP_TRY(hipEventCreate(&b->ev_tr1));
+  }
+  return 0;
+}
+
+template <typename T>
+int launch_all_fills(pw_batch* b, hipStream_t st) {
+  pw::FillParams<T> a;
+  memset(&a, 0, sizeof a);
+  a.pairs = b->d_pairs; a.arena = b->d_arena; a.masks = b->d_masks;
+  a.hdump = (T*)b->d_hdump; a.results = b->d_results; a.subst = (const T*)b->d_subst;
+  a.npairs = b->n; a.L = b->L; a.brule = b->brule; a.endrule = b->endrule;
+  a.banded = b->mode == pw::BANDED_MODE;
+  a.match = (T)b->subst[0]; a.mismatch = (T)(b->L > 1 ? b->subst[1] : b->subst[0]);
+  a.go = (T)b->go; a.ge = (T)b->ge;
+  for (auto& c : b->classes) {
+    a.order = c.d_order;
+    HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pw_last_error(void) { return g_err.c_str(); }
+
+int pw_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+pw_batch* pw_batch_create(int device, const pw_scoring* sc, int32_t n_pairs, const pw_pair* pairs,
+                          uint64_t arena_bytes, uint32_t flags) {
+  if (!sc || n_pairs < 0 || (n_pairs > 0 && !pairs)) { fail("pw_batch_create: bad arguments"); return nullptr; }
+  if (sc->mode != pw::STD_MODE && sc->mode != pw::BANDED_MODE) { fail("unknown alignment mode"); return nullptr; }
+  if (sc->type < 0 || sc->type > (sc->mode == pw::STD_MODE ? 6 : 2)) { fail("unknown alignment type"); return nullptr; }
+  if (sc->alphabet_len < 1 || sc->alphabet_len > 256 || !sc->subst) { fail("alphabet_len must be 1..256 with a score matrix"); return nullptr; }
+  pw_batch* b = new pw_batch();
+  b->device = device; b->n = n_pairs; b->flags = flags;
+  b->mode = sc->mode; b->type = sc->type; b->L = sc->alphabet_len; b->go = sc->go; b->ge = sc->ge;
+  b->subst.assign(sc->subst, sc->subst + (size_t)b->L * b->L);
+  b->pairs.assign(pairs, pairs + n_pairs);
+  b->arena_bytes = arena_bytes;
+  if (batch_build(b) != 0) { batch_free_device(b); delete b; return nullptr; }
+  return b;
+}
+
+void pw_batch_destroy(pw_batch* b) {
+  if (!b) return;
+  batch_free_device(b);
+  delete b;
+}
+
+int pw_batch_init_rc(const pw_batch* b, int32_t k) { return (k < 0 || k >= b->n) ? -1 : b->plans[k].rc; }
+
+int pw_batch_band(const pw_batch* b, int32_t k, int32_t* dmin, int32_t* dmax, int32_t* num_rows) {
+  if (k < 0 || k >= b->n) return -1;
+  if (dmin) *dmin = b->plans[k].dmin;
+  if (dmax) *dmax = b->plans[k].dmax;
+  if (num_rows) *num_rows = b->plans[k].num_rows;
+  return b->plans[k].clamped;
+}
+
+int64_t pw_batch_pair_cells(const pw_batch* b, int32_t k) { return (k < 0 || k >= b->n) ? -1 : b->plans[k].cells; }
+int64_t pw_batch_cells(const pw_batch* b) { return b->cells; }
+int64_t pw_batch_algorithmic_bytes(const pw_batch* b) { return b->alg_bytes; }
+int pw_batch_score_type(const pw_batch* b) { return b->use_f64 ? 1 : 0; }
+
+int pw_batch_upload_arena(pw_batch* b, const uint8_t* host, uint64_t bytes) {
+  if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
+  HIP_TRY(hipSetDevice(b->device));
+  if (bytes) HIP_TRY(hipMemcpy(b->d_arena, host, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
+void* pw_batch_arena_device(pw_batch* b) { return b->d_arena; }
+
+int pw_batch_solve(pw_batch* b, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_fill0, st));
+  const int rc = b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
+  if (rc != 0) return rc;
+  if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_fill1, st)); b->fill_timed = true; }
+  return 0;
+}
+
+static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
+  pw::TraceParams p;
+  memset(&p, 0, sizeof p);
+  p.pairs = b->d_pairs; p.arena = b->d_arena; p.masks = b->d_masks; p.results = b->d_results;
+  p.transcripts = b->d_tx; p.npairs = b->n; p.gosign = b->gosign;
+  p.banded = b->mode == pw::BANDED_MODE; p.ends = d_ends;
+  if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_tr0, st));
+  HIP_TRY(pw::launch_trace(p, st));
+  if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_tr1, st)); b->trace_timed = true; }
+  return 0;
+}
+
+int pw_batch_traceback(pw_batch* b, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  return do_trace(b, nullptr, (hipStream_t)stream);
+}
+
+int pw_batch_traceback_from(pw_batch* b, const int32_t* ends_ij, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (!b->d_ends) HIP_TRY(hipMalloc((void**)&b->d_ends, 8 * std::max<int32_t>(b->n, 1)));
+  // validate on the host: an end cell outside the table would send the walker out of the mask plane
+  for (int32_t k = 0; k < b->n; k++) {
+    if (!b->descs[k].solvable) continue;
+    const int i = ends_ij[2 * k], j = ends_ij[2 * k + 1];
+    if (i < 0 && j < 0) continue;
+    const pw::Plan& pl = b->plans[k];
+    const int X = b->pairs[k].origin_len, Y = b->pairs[k].mutant_len;
+    bool ok;
+    if (b->mode == pw::STD_MODE) ok = i >= 0 && i <= X && j >= 0 && j <= Y;
+    else ok = i >= 0 && i < pl.num_rows && j >= 0 && j < pw::plan_len(X, Y, pl.dmin + i);
+    if (!ok) return fail("traceback end cell outside the table");
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_ends, ends_ij, 8 * (size_t)b->n, hipMemcpyHostToDevice, st));
+  return do_trace(b, b->d_ends, st);
+}
+
+int pw_batch_sync(pw_batch* b, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+void* pw_batch_results_device(pw_batch* b) { return b->d_results; }
+void* pw_batch_transcripts_device(pw_batch* b) { return b->d_tx; }
+uint64_t pw_batch_transcripts_bytes(const pw_batch* b) { return b->tx_bytes; }
+
+int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap) {
+  if (k < 0 || k >= b->n) return -1;
+  if (off) *off = b->descs[k].tx_off;
+  if (cap) *cap = b->descs[k].tx_cap;
+  return 0;
+}
+
+int pw_batch_results(pw_batch* b, pw_result* out) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->n) HIP_TRY(hipMemcpy(out, b->d_results, sizeof(pw_result) * (size_t)b->n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pw_batch_transcripts(pw_batch* b, uint8_t* out) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->tx_bytes) HIP_TRY(hipMemcpy(out, b->d_tx, b->tx_bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pw_batch_scores(pw_batch* b, int32_t k, double* out, int64_t n) {
+  if (!(b->flags & PW_FLAG_DUMP_SCORES) || k < 0 || k >= b->n || !b->descs[k].solvable) return fail("no score plane");
+  const pw::PairDesc& d = b->descs[k];
+  const int64_t want = (int64_t)d.ndiag * d.h_pitch;
+  if (n < want) return fail("score buffer too small");
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->use_f64) {
+    HIP_TRY(hipMemcpy(out, (double*)b->d_hdump + d.h_off, 8 * (size_t)want, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<int32_t> tmp((size_t)want);
+    HIP_TRY(hipMemcpy(tmp.data(), (int32_t*)b->d_hdump + d.h_off, 4 * (size_t)want, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < want; i++) out[i] = (double)tmp[(size_t)i];
+  }
+  return 0;
+}
+
+float pw_batch_fill_ms(pw_batch* b) {
+  if (!b->fill_timed) return -1.f;
+  float ms = -1.f;
+  (void)hipSetDevice(b->device);
+  if (hipEventSynchronize(b->ev_fill1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, b->ev_fill0, b->ev_fill1) != hipSuccess) return -1.f;
+  return ms;
+}
+
+float pw_batch_trace_ms(pw_batch* b) {
+  if (!b->trace_timed) return -1.f;
+  float ms = -1.f;
+  (void)hipSetDevice(b->device);
+  if (hipEventSynchronize(b->ev_tr1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, b->ev_tr0, b->ev_tr1) != hipSuccess) return -1.f;
+  return ms;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// The four drop-in functions (include/pwlib.h): one problem per dptable, solved as a batch of one.
+// =================================================================================================
+namespace {
+
+const uint64_t kMagic = 0x70776c69622d6869ull;   // "pwlib-hi"
+
+// Lives immediately in front of the row-pointer array T->cells points at.
+struct Hidden {
+  uint64_t magic;
+  pw_batch* batch;
+  dpcell* cell_slab;          // all rows, back to back
+  alnchoice* choice_slab;     // materialised choices
+  int64_t ncells;
+  int L;
+  int dmin_c;
+  std::vector<alignment*>* alns;
+};
+
+Hidden* hidden_of(dptable* T) {
+  if (!T || !T->cells) return nullptr;
+  Hidden* h = (Hidden*)((char*)T->cells - sizeof(Hidden));
+  return h->magic == kMagic ? h : nullptr;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dptable_init(dptable* T) {
+  if (!T || !T->prob || !T->prob->frame || !T->prob->scores) return -1;
+  alnprob* prob = T->prob;
+  alnframe* fr = prob->frame;
+  const int X = fr->origin_range.j - fr->origin_range.i, Y = fr->mutant_range.j - fr->mutant_range.i;
+  if (prob->mode != STD_MODE && prob->mode != BANDED_MODE) {
+    printf("Panick in %s (%d): %s\n", "pwlib", __LINE__, "Shouldn't have happened!");   // pw.c:22-23 exits here
+    return -1;
+  }
+  if (X < 0 || Y < 0) { fprintf(stderr, "pwlib: negative frame length\n"); return -1; }
+  if (prob->max_new_mins > 0) {
+    fprintf(stderr, "pwlib: max_new_mins > 0 is not supported (the reference reads uninitialised memory there)\n");
+    return -1;
+  }
+  int type, dmin = 0, dmax = 0;
+  if (prob->mode == STD_MODE) type = (int)prob->std_params->type;
+  else { type = (int)prob->banded_params->type; dmin = prob->banded_params->dmin; dmax = prob->banded_params->dmax; }
+  pw::Plan pl = pw::plan_problem((int)prob->mode, type, X, Y, dmin, dmax);
+  if (prob->mode == BANDED_MODE) {
+    if (pl.clamped) {   // _pw_internals.c:32-35: message on stdout, caller's struct updated
+      printf("Band [%d, %d] exceeds table limits, reduced it to [%d, %d].\n", dmin, dmax, pl.dmin, pl.dmax);
+      prob->banded_params->dmin = pl.dmin; prob->banded_params->dmax = pl.dmax;
+    }
+    if (pl.rc != 0) {
+      if (type == B_GLOBAL && (X - Y > pl.dmax || X - Y < pl.dmin || (int64_t)pl.dmax * pl.dmin > 0))
+        printf("End points not within band for global alignment!\n");            // :41
+      else printf("Invalid band: [%d, %d]!\n", pl.dmin, pl.dmax);                // :47
+      return -1;
+    }
+  }
+  if (pw::plan_pick_bk(pl.ndiag, pw::kSupportedBK, pw::kNumSupportedBK) == 0 && pl.ndiag > 0) {
+    fprintf(stderr, "pwlib: %d diagonals exceed the widest GPU fill kernel (%d); refusing (no CPU fallback)\n",
+            pl.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
+    return -1;
+  }
+  T->num_rows = pl.num_rows;
+  T->row_lens = (int*)malloc(sizeof(int) * (size_t)std::max(pl.num_rows, 1));
+  char* blk = (char*)malloc(sizeof(Hidden) + sizeof(dpcell*) * (size_t)std::max(pl.num_rows, 1));
+  if (!T->row_lens || !blk) { fprintf(stderr, "pwlib: out of memory\n"); free(T->row_lens); free(blk); return -1; }
+  Hidden* h = (Hidden*)blk;
+  h->magic = kMagic; h->batch = nullptr; h->choice_slab = nullptr; h->L = 0; h->dmin_c = pl.dmin;
+  h->alns = new std::vector<alignment*>();
+  h->ncells = pl.cells;
+  h->cell_slab = (dpcell*)calloc((size_t)std::max<int64_t>(pl.cells, 1), sizeof(dpcell));   // all empty (:64-74)
+  if (!h->cell_slab) { fprintf(stderr, "pwlib: out of memory\n"); delete h->alns; free(T->row_lens); free(blk); return -1; }
+  T->cells = (dpcell**)(blk + sizeof(Hidden));
+  int64_t off = 0;
+  for (int i = 0; i < pl.num_rows; i++) {
+    const int len = prob->mode == STD_MODE ? Y + 1 : pw::plan_len(X, Y, pl.dmin + i);
+    T->row_lens[i] = len;
+    T->cells[i] = h->cell_slab + off;
+    off += len;
+  }
+  return 0;
+}
+
+void dptable_free(dptable* T) {
+  Hidden* h = hidden_of(T);
+  if (!h) return;
+  pw_batch_destroy(h->batch);
+  for (alignment* a : *h->alns) { free(a->transcript); free(a); }
+  delete h->alns;
+  free(h->choice_slab);
+  free(h->cell_slab);
+  h->magic = 0;
+  free((char*)T->cells - sizeof(Hidden));
+  free(T->row_lens);
+  T->cells = NULL; T->row_lens = NULL; T->num_rows = -1;
+}
+
+intpair dptable_solve(dptable* T) {
+  const intpair none = {-1, -1};
+  Hidden* h = hidden_of(T);
+  if (!h) { fprintf(stderr, "pwlib: dptable_solve on an uninitialised table\n"); return none; }
+  alnprob* prob = T->prob;
+  alnframe* fr = prob->frame;
+  const int X = fr->origin_range.j - fr->origin_range.i, Y = fr->mutant_range.j - fr->mutant_range.i;
+  if (T->num_rows <= 0) return none;
+  // letters -> one byte each; the alphabet size is not part of the ABI: use the largest letter seen
+  std::vector<uint8_t> arena((size_t)X + Y + 16, 0);
+  int maxlet = 0;
+  for (int i = 0; i < X; i++) { const int c = fr->origin[fr->origin_range.i + i]; if (c < 0 || c > 255) { fprintf(stderr, "pwlib: letter %d out of range 0..255\n", c); return none; } arena[i] = (uint8_t)c; maxlet = std::max(maxlet, c); }
+  for (int i = 0; i < Y; i++) { const int c = fr->mutant[fr->mutant_range.i + i]; if (c < 0 || c > 255) { fprintf(stderr, "pwlib: letter %d out of range 0..255\n", c); return none; } arena[(size_t)X + i] = (uint8_t)c; maxlet = std::max(maxlet, c); }
+  const int L = maxlet + 1;
+  std::vector<double> subst((size_t)L * L);
+  for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) subst[(size_t)i * L + j] = prob->scores->subst_scores[i][j];
+  pw_scoring sc;
+  sc.mode = (int)prob->mode;
+  sc.type = prob->mode == STD_MODE ? (int)prob->std_params->type : (int)prob->banded_params->type;
+  sc.alphabet_len = L; sc.subst = subst.data();
+  sc.go = prob->scores->gap_open_score; sc.ge = prob->scores->gap_extend_score;
+  pw_pair pr;
+  pr.origin_off = 0; pr.mutant_off = (uint64_t)X; pr.origin_len = X; pr.mutant_len = Y;
+  pr.dmin = prob->mode == BANDED_MODE ? prob->banded_params->dmin : 0;
+  pr.dmax = prob->mode == BANDED_MODE ? prob->banded_params->dmax : 0;
+  const bool want_table = prob->mode == STD_MODE && !env_int("PWLIB_NO_TABLE", 0);
+  if (h->batch) { pw_batch_destroy(h->batch); h->batch = nullptr; }
+  h->batch = pw_batch_create(env_int("PWLIB_DEVICE", 0), &sc, 1, &pr, arena.size(), want_table ? PW_FLAG_DUMP_SCORES : 0);
+  if (!h->batch) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); return none; }
+  pw_result res;
+  if (pw_batch_upload_arena(h->batch, arena.data(), arena.size()) != 0 || pw_batch_solve(h->batch, nullptr) != 0 ||
+      pw_batch_sync(h->batch, nullptr) != 0 || pw_batch_results(h->batch, &res) != 0) {
+    fprintf(stderr, "pwlib: %s\n", pw_last_error());
+    return none;
+  }
+  // ---- materialise what the reference's callers read out of C memory ----
+  free(h->choice_slab); h->choice_slab = nullptr;
+  if (want_table) {
+    // every cell's choices[0].score (Aligner.table_scores, pw.py:278-285)
+    const int pitch = std::min(X, Y) + 1;
+    std::vector<double> plane((size_t)(X + Y + 1) * pitch);
+    if (pw_batch_scores(h->batch, 0, plane.data(), (int64_t)plane.size()) != 0) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); return none; }
+    h->choice_slab = (alnchoice*)calloc((size_t)h->ncells, sizeof(alnchoice));
+    if (!h->choice_slab) { fprintf(stderr, "pwlib: out of memory\n"); return none; }
+    for (int x = 0; x <= X; x++) for (int y = 0; y <= Y; y++) {
+      const int64_t c = (int64_t)x * (Y + 1) + y;
+      alnchoice* ch = &h->choice_slab[c];
+      ch->op = 0; ch->base = NULL; ch->mins_cd = prob->max_new_mins; ch->cur_min = 0;
+      ch->score = plane[(size_t)(x - y + Y) * pitch + (size_t)std::min(x, y)];
+      h->cell_slab[c].num_choices = 1; h->cell_slab[c].choices = ch;
+    }
+  } else if (res.opt_i >= 0 && res.opt_j >= 0) {
+    h->choice_slab = (alnchoice*)calloc(1, sizeof(alnchoice));
+    if (!h->choice_slab) { fprintf(stderr, "pwlib: out of memory\n"); return none; }
+    h->choice_slab->score = res.score; h->choice_slab->base = NULL; h->choice_slab->mins_cd = prob->max_new_mins;
+    T->cells[res.opt_i][res.opt_j].num_choices = 1;
+    T->cells[res.opt_i][res.opt_j].choices = h->choice_slab;
+  }
+  intpair opt = {res.opt_i, res.opt_j};
+  return opt;
+}
+
+alignment* dptable_traceback(dptable* T, intpair end) {
+  Hidden* h = hidden_of(T);
+  if (!h || !h->batch) { fprintf(stderr, "pwlib: dptable_traceback before dptable_solve\n"); return NULL; }
+  const int32_t ends[2] = {end.i, end.j};
+  pw_result res;
+  if (pw_batch_traceback_from(h->batch, ends, nullptr) != 0 || pw_batch_sync(h->batch, nullptr) != 0 ||
+      pw_batch_results(h->batch, &res) != 0) {
+    fprintf(stderr, "pwlib: %s\n", pw_last_error());
+    return NULL;
+  }
+  if (!(res.status & PW_ST_TRACED)) return NULL;
+  if (res.status & PW_ST_PANICK) {   // the reference exits the process here (pw.c:132-134)
+    printf("Panick in %s (%d): %s\n", "pwlib", __LINE__, "Shouldn't have happened!");
+    return NULL;
+  }
+  if (res.tx_len == 0) return NULL;  // empty transcript (pw.c:135-138)
+  uint64_t off; int32_t cap;
+  pw_batch_tx_slot(h->batch, 0, &off, &cap);
+  std::vector<uint8_t> tx(pw_batch_transcripts_bytes(h->batch));
+  if (pw_batch_transcripts(h->batch, tx.data()) != 0) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); return NULL; }
+  alignment* a = (alignment*)malloc(sizeof(alignment));
+  a->transcript = (char*)malloc((size_t)res.tx_len + 1);
+  memcpy(a->transcript, tx.data() + off + cap - res.tx_len, (size_t)res.tx_len);
+  a->transcript[res.tx_len] = 0;
+  a->origin_idx = res.origin_idx + T->prob->frame->origin_range.i;
+  a->mutant_idx = res.mutant_idx + T->prob->frame->mutant_range.i;
+  // score of the END cell given (pw.c:148): the solve score for the optimal cell, the materialised
+  // table for any other cell (standard mode), otherwise unknown
+  if (end.i == res.opt_i && end.j == res.opt_j) a->score = res.score;
+  else if (T->cells[end.i][end.j].num_choices > 0) a->score = T->cells[end.i][end.j].choices[0].score;
+  else a->score = NAN;
+  h->alns->push_back(a);
+  return a;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+/* pw_batch.h -- batch entry points of libpwlib (pwlib.so): many independent alignment problems per call.
+ *
+ * NEW SURFACE (no reference counterpart): the reference solves one pair per dptable (pw.c:47-114) and
+ * has no batch call.  These functions sit beside the four drop-in functions of pwlib.h
+ * in the same shared object; per pair they compute exactly what
+ *     dptable_init -> dptable_solve -> dptable_traceback(T, opt)
+ * computes (reference pw.c:10-26, 47-114, 116-151), for a whole batch in a handful of kernel launches.
+ *
+ * Plain C ABI: pointers and sizes only.  Sequences are passed as one byte per letter in a single
+ * "arena"; pairs reference frames of it by offset and length (the reference's alnframe
+ * origin_range/mutant_range, pwlib.h:84-89, already applied).  `stream` arguments are a hipStream_t
+ * passed as void* (NULL = the default stream); device pointers are ordinary device addresses, so a
+ * caller may hand in memory it owns (e.g. a torch tensor's data_ptr()).
+ */
+#ifndef PW_BATCH_H
+#define PW_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pw_batch pw_batch;
+
+/* Scoring shared by all pairs of a batch (the reference's alnscores, pwlib.h:71-78, plus mode/type). */
+typedef struct {
+  int mode;             /* alnmode:  0 STD_MODE, 1 BANDED_MODE */
+  int type;             /* std_alntype 0..6 or banded_alntype 0..2 */
+  int alphabet_len;     /* L; letters are 0 .. L-1, L <= 256 */
+  const double* subst;  /* row-major L x L, subst[o*L + m] = subst_scores[o][m] */
+  double go, ge;        /* gap open / gap extend scores */
+} pw_scoring;
+
+/* One problem. */
+typedef struct {
+  uint64_t origin_off;  /* byte offset of the origin frame in the arena */
+  uint64_t mutant_off;  /* byte offset of the mutant frame in the arena */
+  int32_t origin_len;   /* X */
+  int32_t mutant_len;   /* Y */
+  int32_t dmin, dmax;   /* banded mode: diag_range as given (it is clamped like _pw_internals.c:29-36) */
+} pw_pair;
+
+/* One result; 32 bytes.  Identical on host and device: this is the record a multi-GPU gather moves. */
+typedef struct {
+  double score;         /* cells[opt].choices[0].score */
+  int32_t opt_i, opt_j; /* what dptable_solve returns: (x,y) in STD mode, (d-dmin, a) in banded mode; -1,-1 = none */
+  int32_t origin_idx;   /* alignment start relative to the frame start (add origin_range.i) */
+  int32_t mutant_idx;
+  int32_t tx_len;       /* transcript length (0 if none) */
+  int32_t status;       /* PW_ST_* bits */
+} pw_result;
+
+#define PW_ST_TRACED 1  /* traceback ran for this pair */
+#define PW_ST_EMPTY 2   /* empty transcript: the reference's dptable_traceback returns NULL (pw.c:135-138) */
+#define PW_ST_PANICK 4  /* the reference would exit(1) here (pw.c:132-134) */
+
+/* flags of pw_batch_create */
+#define PW_FLAG_DUMP_SCORES 1   /* also write the score of every cell (for table_scores-style callers) */
+#define PW_FLAG_FORCE_F64 2     /* compute in double even if all scores are small integers */
+#define PW_FLAG_FORCE_GENERIC 4 /* use the run-time-everything kernel (testing) */
+#define PW_FLAG_PROFILE 8       /* bracket every fill launch with HIP events (pw_batch_fill_ms) */
+
+const char* pw_last_error(void);
+int pw_device_count(void);
+
+/* Plans the batch (band clamp / feasibility per pair exactly as dptable_init), picks the kernel variants,
+ * allocates every device buffer and uploads the descriptors.  The arena is `arena_bytes` long; its
+ * contents are supplied later (pw_batch_upload_arena or pw_batch_arena_device).  NULL on error. */
+pw_batch* pw_batch_create(int device, const pw_scoring* scoring, int32_t n_pairs, const pw_pair* pairs,
+                          uint64_t arena_bytes, uint32_t flags);
+void pw_batch_destroy(pw_batch* b);
+
+/* per-pair planning results (host side, available right after create) */
+int pw_batch_init_rc(const pw_batch* b, int32_t k);                         /* 0 or -1, as dptable_init */
+int pw_batch_band(const pw_batch* b, int32_t k, int32_t* dmin, int32_t* dmax, int32_t* num_rows);
+int64_t pw_batch_pair_cells(const pw_batch* b, int32_t k);                   /* cells the reference allocates */
+int64_t pw_batch_cells(const pw_batch* b);                                   /* sum over solvable pairs */
+int64_t pw_batch_algorithmic_bytes(const pw_batch* b);                       /* 0.5 B/cell + X+Y + 32 per pair */
+int pw_batch_score_type(const pw_batch* b);                                  /* 0 int32, 1 double */
+
+int pw_batch_upload_arena(pw_batch* b, const uint8_t* host_arena, uint64_t bytes);   /* synchronous H2D */
+void* pw_batch_arena_device(pw_batch* b);
+
+/* K1 (+ end-cell search): asynchronous on `stream`. */
+int pw_batch_solve(pw_batch* b, void* stream);
+/* K4 from each pair's optimal cell: asynchronous on `stream`, after pw_batch_solve on the same stream. */
+int pw_batch_traceback(pw_batch* b, void* stream);
+/* K4 from explicit end cells (table coordinates i,j per pair, host array of 2*n_pairs ints). */
+int pw_batch_traceback_from(pw_batch* b, const int32_t* ends_ij, void* stream);
+int pw_batch_sync(pw_batch* b, void* stream);
+
+/* results: device-resident buffers and D2H copies */
+void* pw_batch_results_device(pw_batch* b);            /* pw_result[n_pairs] */
+void* pw_batch_transcripts_device(pw_batch* b);        /* transcript slots, see pw_batch_tx_slot */
+uint64_t pw_batch_transcripts_bytes(const pw_batch* b);
+int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap); /* ops of pair k end at off+cap */
+int pw_batch_results(pw_batch* b, pw_result* host_out);                          /* synchronous D2H */
+int pw_batch_transcripts(pw_batch* b, uint8_t* host_out);                        /* synchronous D2H of all slots */
+/* score plane of pair k (PW_FLAG_DUMP_SCORES): out[(d-dmin)*pitch + a], pitch = min(X,Y)+1, as doubles */
+int pw_batch_scores(pw_batch* b, int32_t k, double* host_out, int64_t n);
+
+/* mean duration (ms) of the fill kernel launches of the last pw_batch_solve (PW_FLAG_PROFILE), and
+ * of the dominant launch alone; < 0 if unavailable.  Synchronises on the recorded events. */
+float pw_batch_fill_ms(pw_batch* b);
+float pw_batch_trace_ms(pw_batch* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

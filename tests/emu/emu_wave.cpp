@@ -1,0 +1,183 @@
+// tests/emu/emu_wave.cpp -- TEST INFRASTRUCTURE ONLY: a lockstep CPU emulator of one 64-lane wavefront.
+//
+// It compiles the *same* lane program the gfx950 kernels are built from (biseqt_amd/csrc/pw_wave.h)
+// and the same host planner (pw_plan.h), and runs the 64 lanes as 64 ucontext fibers that meet at
+// every cross-lane operation.  Purpose: debug the indexing / tie-break logic of the kernel on the CPU
+// (this container has no GPU) by comparing it with the oracle.  It is never linked into the product
+// library and the product never falls back to it.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define PW_FN inline
+#include "../../biseqt_amd/csrc/pw_wave.h"
+#include "../../biseqt_amd/csrc/pw_plan.h"
+
+namespace {
+
+struct Emu {
+  static const int N = 64;
+  ucontext_t main_ctx, ctx[N];
+  std::vector<char> stacks[N];
+  bool done[N];
+  int cur;
+  int xch[2][N];
+  unsigned phase[N];
+  std::function<void()> body;
+  static Emu* self;
+
+  static void tramp() {
+    Emu* e = self;
+    e->body();
+    e->done[e->cur] = true;
+    swapcontext(&e->ctx[e->cur], &e->main_ctx);
+  }
+  void run(std::function<void()> fn) {
+    body = fn;
+    self = this;
+    for (int l = 0; l < N; l++) {
+      stacks[l].resize(1 << 18);
+      done[l] = false; phase[l] = 0;
+      getcontext(&ctx[l]);
+      ctx[l].uc_stack.ss_sp = stacks[l].data();
+      ctx[l].uc_stack.ss_size = stacks[l].size();
+      ctx[l].uc_link = &main_ctx;
+      makecontext(&ctx[l], (void (*)())tramp, 0);
+    }
+    bool any = true;
+    while (any) {
+      any = false;
+      for (int l = 0; l < N; l++) {
+        if (done[l]) continue;
+        cur = l;
+        swapcontext(&main_ctx, &ctx[l]);
+        any = true;
+      }
+    }
+  }
+  void barrier() { int l = cur; swapcontext(&ctx[l], &main_ctx); }
+  int exchange(int v, int src_lane, int old) {
+    const int l = cur;
+    const unsigned ph = phase[l]++ & 1u;
+    xch[ph][l] = v;
+    barrier();
+    cur = l;   // (the scheduler sets cur before resuming; keep the local view explicit)
+    return (src_lane >= 0 && src_lane < N) ? xch[ph][src_lane] : old;
+  }
+};
+Emu* Emu::self = nullptr;
+
+struct EmuP {
+  static int lane() { return Emu::self->cur; }
+  static int32_t shr1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur - 1, old); }
+  static int32_t shl1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, old); }
+  static int32_t shfl_xor(int32_t v, int m) { Emu* e = Emu::self; return e->exchange(v, e->cur ^ m, 0); }
+};
+
+template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
+void run_fill(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst) {
+  Emu emu;
+  emu.run([&]() {
+    pw::WaveFill<EmuP, T, BK, BANY, TRACK, GENERIC> w(a, pd, subst);
+    w.pair_slot = 0;
+    w.run();
+  });
+}
+
+template <typename T, int BK>
+void dispatch_variant(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst, int generic,
+                      int bany, int track) {
+  if (generic) run_fill<T, BK, false, true, true>(a, pd, subst);
+  else if (bany && track) run_fill<T, BK, true, true, false>(a, pd, subst);
+  else if (!bany && track) run_fill<T, BK, false, true, false>(a, pd, subst);
+  else if (!bany && !track) run_fill<T, BK, false, false, false>(a, pd, subst);
+  else run_fill<T, BK, true, true, false>(a, pd, subst);   // (bany, !track): END_ANCHORED rides on (1,1)
+}
+
+template <typename T>
+int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int Y, int L,
+            const double* subst, double go, double ge, int dmin_in, int dmax_in, int force_generic, int bk,
+            int* info, double* score, char* txbuf, int txcap, double* hdump) {
+  pw::Plan pl = pw::plan_problem(mode, type, X, Y, dmin_in, dmax_in);
+  info[0] = pl.rc; info[1] = pl.dmin; info[2] = pl.dmax; info[3] = pl.num_rows;
+  info[4] = -1; info[5] = -1; info[6] = 0; info[7] = 0; info[8] = 0; info[9] = 0;
+  if (pl.rc != 0) return 0;
+  if (pl.ndiag <= 0) return 0;
+  if ((int64_t)64 * bk < pl.ndiag) return -3;
+  // arena: origin at 0, mutant after it, both padded
+  const int opad = ((X > 0 ? X : 1) + 31) / 16 * 16;
+  const int mpad = ((Y > 0 ? Y : 1) + 31) / 16 * 16;
+  std::vector<uint8_t> arena(opad + mpad, 0);
+  for (int i = 0; i < X; i++) arena[i] = (uint8_t)origin[i];
+  for (int i = 0; i < Y; i++) arena[opad + i] = (uint8_t)mutant[i];
+  pw::PairDesc pd;
+  memset(&pd, 0, sizeof pd);
+  pd.o_off = 0; pd.m_off = opad; pd.mask_off = 0; pd.h_off = 0; pd.tx_off = 0;
+  pd.X = X; pd.Y = Y; pd.dmin = pl.dmin; pd.ndiag = pl.ndiag; pd.s0 = pl.s0;
+  pd.nblocks = pl.nblocks; pd.steady_b0 = pl.steady_b0; pd.steady_b1 = pl.steady_b1;
+  pd.h_pitch = (X < Y ? X : Y) + 1;
+  pd.tx_cap = X + Y + 1; pd.bk = bk; pd.solvable = 1;
+  std::vector<uint32_t> masks((size_t)pl.nblocks * 64 * bk + 64, 0xdeadbeefu);
+  std::vector<T> hd;
+  if (hdump) hd.assign((size_t)pl.ndiag * pd.h_pitch, T(0));
+  std::vector<T> sub((size_t)L * L);
+  bool simple = true;
+  for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) {
+    sub[(size_t)i * L + j] = (T)subst[(size_t)i * L + j];
+    if (subst[(size_t)i * L + j] != (i == j ? subst[0] : (L > 1 ? subst[1] : subst[0]))) simple = false;
+  }
+  pw::Result res;
+  memset(&res, 0, sizeof res);
+  pw::FillParams<T> a;
+  memset(&a, 0, sizeof a);
+  a.pairs = &pd; a.order = nullptr; a.arena = arena.data(); a.masks = masks.data();
+  a.hdump = hdump ? hd.data() : nullptr; a.results = &res; a.subst = sub.data();
+  a.npairs = 1; a.L = L; a.brule = pl.brule; a.endrule = pl.endrule; a.banded = (mode == pw::BANDED_MODE);
+  a.match = sub[0]; a.mismatch = L > 1 ? sub[1] : sub[0]; a.go = (T)go; a.ge = (T)ge;
+  const int generic = force_generic || !simple || go > 0 || hdump != nullptr;
+  const int bany = pl.brule == pw::BRULE_ANY;
+  const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
+  switch (bk) {
+    case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track); break;
+    case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track); break;
+    case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track); break;
+    case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track); break;
+    case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track); break;
+    default: return -4;
+  }
+  // traceback by "one lane"
+  std::vector<uint8_t> tx((size_t)pd.tx_cap + 1, 0);
+  pw::TraceParams tp;
+  memset(&tp, 0, sizeof tp);
+  tp.pairs = &pd; tp.arena = arena.data(); tp.masks = masks.data(); tp.results = &res;
+  tp.transcripts = tx.data(); tp.npairs = 1;
+  tp.gosign = go < 0 ? -1 : (go > 0 ? 1 : 0); tp.banded = a.banded; tp.ends = nullptr;
+  pw::trace_pair(tp, 0);
+  info[4] = res.opt_i; info[5] = res.opt_j; info[6] = res.origin_idx; info[7] = res.mutant_idx;
+  info[8] = res.tx_len; info[9] = res.status;
+  *score = res.score;
+  if (res.tx_len > 0 && res.tx_len < txcap) {
+    memcpy(txbuf, tx.data() + pd.tx_cap - res.tx_len, (size_t)res.tx_len);
+    txbuf[res.tx_len] = 0;
+  } else if (txcap > 0) txbuf[0] = 0;
+  if (hdump) for (size_t i = 0; i < hd.size(); i++) hdump[i] = (double)hd[i];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int emu_solve(int mode, int type, const int* origin, int X, const int* mutant, int Y, int L,
+                         const double* subst, double go, double ge, int dmin, int dmax, int use_double,
+                         int force_generic, int bk, int* info, double* score, char* txbuf, int txcap,
+                         double* hdump) {
+  if (use_double)
+    return solve_T<double>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk,
+                           info, score, txbuf, txcap, hdump);
+  return solve_T<int32_t>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk,
+                          info, score, txbuf, txcap, hdump);
+}
