@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Headline benchmark: GCUPS of banded local alignment (BASELINE.json config 2) on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (fill + end-cell search + traceback, pw_batch_solve +
+pw_batch_traceback) over one batch of 10 000 synthetic 2 kb x ~2 kb pairs, band radius 200, B_LOCAL,
+scores match 1 / mismatch -3 / gap open -5 / gap extend -2, inputs resident in HBM.  With N > 1 every
+rank holds its own batch of the same shape (pairs dealt round-robin from an N-times larger job: weak
+scaling) and each step ends with the gather of the 32-byte result records to rank 0 over RCCL.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the fill kernel (the dominant kernel) with the
+algorithmic bytes of SURVEY.md 8d -- 0.5 B per cell (4-bit tie mask) + X + Y + 32 B per pair + the
+transcript bytes -- over its mean duration measured with HIP events on the launch stream inside the
+library.  `cpu_baseline` times the reference pwlib itself (oracle/_ref, compiled from the reference
+sources) -- or the oracle restatement if that file is absent -- on the host cores, on a bounded sample
+of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PAIRS, LENGTH, RADIUS = 10000, 2000, 200
+SCORES = dict(match=1., mismatch=-3., go=-5., ge=-2.)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N == 1): the reference library on the host cores, bounded sample
+# ---------------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    kind, seed, first, count, budget_s = args
+    sys.path.insert(0, ROOT)
+    from biseqt_amd import synth
+    origins, mutants = synth.pair_batch(seed, first + count, LENGTH)
+    cells = 0
+    t0 = time.time()
+    done = 0
+    if kind == 'reference':
+        from oracle import ref_driver as R
+        lib = R.load()
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)           # the reference prints band messages to stdout
+        for k in range(first, first + count):
+            P = R.Problem(origins[k].tolist(), mutants[k].tolist(), mode=R.BANDED_MODE, alntype=R.B_LOCAL,
+                          diag_range=(-RADIUS, RADIUS), L=4, **SCORES)
+            R.run(lib, P)              # init + solve + traceback + free, as pw.py drives it
+            cells += synth.banded_cells(len(origins[k]), len(mutants[k]), -RADIUS, RADIUS)
+            done += 1
+            if time.time() - t0 > budget_s:
+                break
+    else:
+        from oracle import oracle as O
+        for k in range(first, first + count):
+            O.solve(origins[k], mutants[k], L=4, mode=1, alntype=O.B_LOCAL, diag_range=(-RADIUS, RADIUS), **SCORES)
+            cells += synth.banded_cells(len(origins[k]), len(mutants[k]), -RADIUS, RADIUS)
+            done += 1
+            if time.time() - t0 > budget_s:
+                break
+    return cells, done, time.time() - t0
+
+
+def cpu_baseline(budget_s=12.0):
+    import multiprocessing as mp
+    kind = 'reference' if os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'pwlib_ref.so')) else 'port'
+    if kind == 'port':
+        from oracle import oracle as O
+        O.lib()
+    cores = min(os.cpu_count() or 1, 16)
+    per = 64
+    ctx = mp.get_context('spawn')     # never fork a process that may touch the GPU
+    t0 = time.time()
+    with ctx.Pool(cores) as pool:
+        out = pool.map(_cpu_worker, [(kind, 2, c * per, per, budget_s) for c in range(cores)])
+    wall = time.time() - t0
+    cells = sum(o[0] for o in out)
+    npairs = sum(o[1] for o in out)
+    busy = max(o[2] for o in out)
+    return dict(value=cells / busy / 1e9, unit='GCUPS', cores=cores, kind=kind,
+                sample='%d pairs of the cfg2 batch (2 kb x ~2 kb, band radius 200, B_LOCAL), %d single-threaded '
+                       'processes, init+solve+traceback+free per pair, %.1f s busy / %.1f s wall'
+                       % (npairs, cores, busy, wall))
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (default: the BASELINE config)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()           # before anything touches the GPU
+
+    import torch
+    import torch.distributed as dist
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner, RESULT_DTYPE
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    # rank r owns pairs r, r + world, ... of a job of world * pairs pairs (round-robin shard)
+    n_local = args.pairs
+    origins, mutants = synth.pair_batch(2 + 1000 * rank, n_local, LENGTH)
+    batch = BatchAligner(list(zip(origins, mutants)), alnmode=W.BANDED_MODE, alntype=W.B_LOCAL, alphabet_len=4,
+                         diag_range=(-RADIUS, RADIUS), match_score=SCORES['match'],
+                         mismatch_score=SCORES['mismatch'], go_score=SCORES['go'], ge_score=SCORES['ge'],
+                         device=local_rank, flags=W.PW_FLAG_PROFILE)
+    cells = batch.cells
+    stream = torch.cuda.current_stream().cuda_stream
+    res_dev = torch.as_tensor(batch.results_device(), device=dev) if world > 1 else None
+    gathered = [torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] \
+        if (world > 1 and rank == 0) else None
+
+    def step():
+        batch.solve(stream)
+        batch.traceback(stream)
+        if world > 1:
+            dist.gather(res_dev, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    fill_ms, trace_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-kernel durations (HIP events recorded by the library on the launch stream): sample a few
+    # extra steps outside the timed region so that reading the events never stalls the pipeline
+    for _ in range(min(5, max(1, args.steps))):
+        batch.solve(stream)
+        batch.traceback(stream)
+        batch.sync(stream)
+        fill_ms.append(batch.fill_ms())
+        trace_ms.append(batch.trace_ms())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    res = batch.results()
+    tx_bytes = int(res['tx_len'].sum())
+    alg_bytes = batch.algorithmic_bytes + tx_bytes
+    fill = float(np.mean(fill_ms))
+    # parity spot check inside the bench: re-score a few transcripts (cheap, size-independent)
+    ok = bool((res['status'] & 1).all() and (res['opt_i'] >= 0).all())
+
+    if rank == 0:
+        total_cells = cells * world
+        value = total_cells * args.steps / elapsed / 1e9
+        achieved = alg_bytes / (fill * 1e-3) / 1e9
+        line = {
+            'metric': 'GCUPS (DP cell updates/s) banded local align',
+            'value': round(value, 3), 'unit': 'GCUPS', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'i32' if batch.score_dtype == 'i32' else 'f64', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: %d pairs/GPU, %d x ~%d, band radius %d, B_LOCAL, '
+                                   'match 1 / mismatch -3 / go -5 / ge -2, fill + end-cell search + traceback%s'
+                                   % (n_local, LENGTH, LENGTH, RADIUS,
+                                      ' + RCCL gather of result records' if world > 1 else ''),
+                       'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'parallelism': 'pairs round-robin x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': None,
+                         'kernel': 'k_fill<int32, BK=8, begin-anywhere, track>',
+                         'kernel_ms': round(fill, 4), 'algorithmic_bytes_per_launch': int(alg_bytes),
+                         'kernel_gcups': round(cells / (fill * 1e-3) / 1e9, 2),
+                         'traceback_kernel_ms': round(float(np.mean(trace_ms)), 4)},
+            'results_ok': ok,
+        }
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,241 @@
+"""Batches of independent alignment problems on one GPU (host side of include/pw_batch.h).
+
+No reference counterpart: the reference solves one pair per ``Aligner`` (``biseqt/pw.py:119-319``).
+Per pair a batch computes exactly what ``Aligner.solve()`` + ``Aligner.traceback()`` compute, for
+all pairs in a handful of kernel launches.  Keyword arguments keep the reference's names
+(``alnmode``, ``alntype``, ``subst_scores``, ``match_score``, ``mismatch_score``, ``go_score``,
+``ge_score``, ``diag_range``).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _pwlib as W
+from .sequence import Sequence
+
+RESULT_DTYPE = np.dtype([('score', '<f8'), ('opt_i', '<i4'), ('opt_j', '<i4'),
+                         ('origin_idx', '<i4'), ('mutant_idx', '<i4'),
+                         ('tx_len', '<i4'), ('status', '<i4')])
+assert RESULT_DTYPE.itemsize == 32
+
+
+def _as_u8(seq):
+    if isinstance(seq, Sequence):
+        return seq.as_array(np.uint8)
+    a = np.asarray(seq)
+    assert a.ndim == 1
+    if a.size:
+        assert a.min() >= 0 and a.max() <= 255, 'letters must be 0..255'
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class DeviceBuffer(object):
+    """A view of device memory owned by a batch, exportable to torch without a copy
+    (``torch.as_tensor(buf, device='cuda')``) through ``__cuda_array_interface__``."""
+
+    def __init__(self, ptr, nbytes, owner):
+        self.ptr, self.nbytes, self.owner = ptr, nbytes, owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=(self.nbytes,), typestr='|u1', data=(self.ptr, False), version=2)
+
+
+class BatchAligner(object):
+    """Plan, upload, solve and trace back a batch of pairs.
+
+    Args:
+        pairs: iterable of ``(origin, mutant)``; each a :class:`Sequence` or an array of letter indices.
+    Keyword Args:
+        alphabet_len (int): number of letters (default: from the first Sequence, else max letter + 1).
+        alnmode, alntype, subst_scores, match_score, mismatch_score, go_score, ge_score: as ``Aligner``.
+        diag_range: one ``(dmin, dmax)`` for all pairs or a list with one per pair (banded mode).
+        device (int): HIP device ordinal.  flags (int): ``PW_FLAG_*`` of include/pw_batch.h.
+        check_band (bool): apply the reference's Python-side ``diag_range`` assertion (default True).
+    """
+
+    def __init__(self, pairs, **kw):
+        self.lib = W.load()
+        self.alnmode = kw.get('alnmode', W.STD_MODE)
+        self.alntype = kw.get('alntype', W.GLOBAL)
+        pairs = list(pairs)
+        self.n = len(pairs)
+        L = kw.get('alphabet_len')
+        seqs = []
+        for (o, m) in pairs:
+            if L is None and isinstance(o, Sequence):
+                L = len(o.alphabet)
+            seqs.append((_as_u8(o), _as_u8(m)))
+        if L is None:
+            L = 1 + max([0] + [int(s.max()) for p in seqs for s in p if s.size])
+        self.L = L
+        subst = kw.get('subst_scores')
+        if subst is None:
+            match, mismatch = kw.get('match_score', 1), kw.get('mismatch_score', 0)
+            subst = [[match if i == j else mismatch for i in range(L)] for j in range(L)]
+        assert len(subst) == L
+        self.subst_scores = subst
+        self.go_score, self.ge_score = kw.get('go_score', 0), kw.get('ge_score', 0)
+        dr = kw.get('diag_range')
+        if self.alnmode == W.BANDED_MODE:
+            assert dr is not None, 'banded mode needs diag_range'
+            drs = [dr] * self.n if (len(dr) == 2 and not hasattr(dr[0], '__len__')) else list(dr)
+            assert len(drs) == self.n
+        else:
+            drs = [(0, 0)] * self.n
+        # arena: every sequence on a 16-byte boundary
+        offs, total = [], 0
+        for (o, m) in seqs:
+            oo = total
+            total += (len(o) + 15) // 16 * 16 + 16
+            mo = total
+            total += (len(m) + 15) // 16 * 16 + 16
+            offs.append((oo, mo))
+        self.arena = np.zeros(max(total, 16), np.uint8)
+        self._pairs = (W.pw_pair * max(self.n, 1))()
+        for k, ((o, m), (oo, mo), (dmin, dmax)) in enumerate(zip(seqs, offs, drs)):
+            self.arena[oo:oo + len(o)] = o
+            self.arena[mo:mo + len(m)] = m
+            if self.alnmode == W.BANDED_MODE and kw.get('check_band', True):
+                # the reference's Python-side check (pw.py:224-226); check_band=False hands the band to
+                # the C side unchecked, which clamps / rejects it like dptable_init
+                assert -len(m) <= dmin <= dmax <= len(o), 'diag_range outside the table'
+            self._pairs[k] = W.pw_pair(oo, mo, len(o), len(m), int(dmin), int(dmax))
+        self.lens = [(len(o), len(m)) for (o, m) in seqs]
+        S = np.ascontiguousarray(np.asarray(subst, dtype=np.float64).reshape(L, L))
+        self._S = S
+        sc = W.pw_scoring(self.alnmode, self.alntype, L, S.ctypes.data_as(C.POINTER(C.c_double)),
+                          float(self.go_score), float(self.ge_score))
+        self.device = kw.get('device', 0)
+        self.flags = kw.get('flags', 0)
+        self.handle = self.lib.pw_batch_create(self.device, C.byref(sc), self.n, self._pairs,
+                                               self.arena.nbytes, self.flags)
+        if not self.handle:
+            raise RuntimeError('pw_batch_create failed: ' + W.last_error())
+        if kw.get('upload', True):
+            self.upload()
+
+    # ---- lifecycle ----
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.pw_batch_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed: %s' % (what, W.last_error()))
+
+    # ---- planning info ----
+    @property
+    def cells(self):
+        """Cells the reference would allocate for the batch: the GCUPS denominator."""
+        return self.lib.pw_batch_cells(self.handle)
+
+    @property
+    def algorithmic_bytes(self):
+        return self.lib.pw_batch_algorithmic_bytes(self.handle)
+
+    @property
+    def score_dtype(self):
+        return 'f64' if self.lib.pw_batch_score_type(self.handle) else 'i32'
+
+    def init_rc(self, k):
+        return self.lib.pw_batch_init_rc(self.handle, k)
+
+    def band(self, k):
+        a, b, r = C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.pw_batch_band(self.handle, k, C.byref(a), C.byref(b), C.byref(r))
+        return a.value, b.value, r.value
+
+    # ---- data movement and kernels ----
+    def upload(self):
+        self._ck(self.lib.pw_batch_upload_arena(self.handle, self.arena.ctypes.data, self.arena.nbytes),
+                 'pw_batch_upload_arena')
+
+    def solve(self, stream=None):
+        self._ck(self.lib.pw_batch_solve(self.handle, stream), 'pw_batch_solve')
+
+    def traceback(self, stream=None):
+        self._ck(self.lib.pw_batch_traceback(self.handle, stream), 'pw_batch_traceback')
+
+    def traceback_from(self, ends, stream=None):
+        e = np.ascontiguousarray(np.asarray(ends, dtype=np.int32).reshape(self.n, 2))
+        self._ck(self.lib.pw_batch_traceback_from(self.handle, e.ctypes.data_as(C.POINTER(C.c_int32)), stream),
+                 'pw_batch_traceback_from')
+
+    def sync(self, stream=None):
+        self._ck(self.lib.pw_batch_sync(self.handle, stream), 'pw_batch_sync')
+
+    def run(self, stream=None):
+        """solve + traceback + sync; returns ``results()``."""
+        self.solve(stream)
+        self.traceback(stream)
+        self.sync(stream)
+        return self.results()
+
+    # ---- results ----
+    def results(self):
+        """Structured array (RESULT_DTYPE), one record per pair (synchronous D2H)."""
+        out = np.zeros(max(self.n, 1), RESULT_DTYPE)
+        self._ck(self.lib.pw_batch_results(self.handle, out.ctypes.data), 'pw_batch_results')
+        return out[:self.n]
+
+    def transcripts(self, results=None):
+        """List with one transcript string (or None) per pair (synchronous D2H)."""
+        res = self.results() if results is None else results
+        nb = self.lib.pw_batch_transcripts_bytes(self.handle)
+        buf = np.zeros(max(nb, 1), np.uint8)
+        self._ck(self.lib.pw_batch_transcripts(self.handle, buf.ctypes.data), 'pw_batch_transcripts')
+        out = []
+        off, cap = C.c_uint64(), C.c_int32()
+        for k in range(self.n):
+            n = int(res['tx_len'][k])
+            if n <= 0:
+                out.append(None)
+                continue
+            self.lib.pw_batch_tx_slot(self.handle, k, C.byref(off), C.byref(cap))
+            end = off.value + cap.value
+            out.append(buf[end - n:end].tobytes().decode('ascii'))
+        return out
+
+    def scores_plane(self, k):
+        """Score of every cell of pair k as ``plane[d - dmin, a]`` (needs PW_FLAG_DUMP_SCORES)."""
+        X, Y = self.lens[k]
+        dmin, dmax, _ = self.band(k)
+        nd, pitch = dmax - dmin + 1, min(X, Y) + 1
+        out = np.zeros(nd * pitch, np.float64)
+        self._ck(self.lib.pw_batch_scores(self.handle, k, out.ctypes.data_as(C.POINTER(C.c_double)), out.size),
+                 'pw_batch_scores')
+        return out.reshape(nd, pitch)
+
+    def results_device(self):
+        return DeviceBuffer(self.lib.pw_batch_results_device(self.handle), 32 * self.n, self)
+
+    def transcripts_device(self):
+        return DeviceBuffer(self.lib.pw_batch_transcripts_device(self.handle),
+                            self.lib.pw_batch_transcripts_bytes(self.handle), self)
+
+    def fill_ms(self):
+        return float(self.lib.pw_batch_fill_ms(self.handle))
+
+    def trace_ms(self):
+        return float(self.lib.pw_batch_trace_ms(self.handle))
+
+
+def align_batch(pairs, **kw):
+    """One-call convenience: returns ``(results, transcripts)`` for the pairs."""
+    with BatchAligner(pairs, **kw) as b:
+        res = b.run()
+        return res, b.transcripts(res)

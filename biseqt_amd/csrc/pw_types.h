@@ -68,7 +68,7 @@ struct Result {
                        // pw.c:135-138); bit 2: the reference would exit(1) here (pw.c:132-134)
 };
 
-enum { ST_TRACED = 1, ST_EMPTY = 2, ST_PANICK = 4 };
+enum { ST_TRACED = 1, ST_EMPTY = 2, ST_PANICK = 4, ST_BADPATH = 8 };
 
 // Uniform parameters of one fill launch.  T is the score type (int32_t or double).
 template <typename T>

@@ -398,7 +398,7 @@ PW_FN void trace_pair(const TraceParams& p, int pair) {
   const uint8_t* mseq = p.arena + pd.m_off;
   uint8_t* tx = p.transcripts + pd.tx_off;
   int pos = pd.tx_cap;            // ops are written backwards, ending right-aligned in the slot
-  int nms = 0;
+  int nms = 0, bad = 0;
   uint32_t mask = pw_mask_at(p, pd, x, y);
   int op = pw_first_op(mask);     // choices[0] of the end cell (pw.c:123)
   while (op != 0 && pos > 0) {
@@ -407,6 +407,10 @@ PW_FN void trace_pair(const TraceParams& p, int pair) {
     else if (op == 1) { ch = 'D'; x--; }
     else { ch = 'I'; y--; }
     tx[--pos] = ch;
+    // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
+    // instead of reading out of bounds
+    const int dd = x - y - pd.dmin;
+    if (x < 0 || y < 0 || dd < 0 || dd >= pd.ndiag) { bad = 1; break; }
     const uint32_t pm = pw_mask_at(p, pd, x, y);
     if (op == 3 || p.gosign == 0) op = pw_first_op(pm);
     else if (p.gosign < 0) op = (pm & (1u << op)) ? op : pw_first_op(pm);
@@ -414,7 +418,7 @@ PW_FN void trace_pair(const TraceParams& p, int pair) {
   }
   r.origin_idx = x; r.mutant_idx = y;
   r.tx_len = pd.tx_cap - pos;
-  r.status = ST_TRACED | (r.tx_len == 0 ? ST_EMPTY : 0) | ((x + y + nms <= 0) ? ST_PANICK : 0);
+  r.status = ST_TRACED | (r.tx_len == 0 ? ST_EMPTY : 0) | ((x + y + nms <= 0) ? ST_PANICK : 0) | (bad ? ST_BADPATH : 0);
   p.results[pair] = r;
 }
 

@@ -1,0 +1,80 @@
+"""Multi-GPU batches: one process per GPU, pairs dealt round-robin, one gather of the results.
+
+Independent sequence pairs are the natural shard: pair ``p`` goes to rank
+``p mod world``; for batches of uneven pairs the list is first sorted by table size so the deal is
+balanced.  There is no collective on the data path; the only exchange is the final gather of the
+fixed 32-byte result records (and, optionally, the transcripts) to rank 0 through
+``torch.distributed`` -- backend ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
+The traffic is KBs-MBs and latency-bound: every rank talks to the root over its own direct xGMI link,
+so a plain gather (not a ring) is the right shape.
+"""
+import numpy as np
+
+from .batch import RESULT_DTYPE
+
+
+def shard_indices(n_pairs, rank, world, weights=None):
+    """Indices of the pairs rank ``rank`` owns.  Round-robin; with ``weights`` (e.g. cells per pair)
+    the pairs are dealt heaviest first so every rank gets a similar load."""
+    if weights is None:
+        return np.arange(rank, n_pairs, world)
+    order = np.argsort(-np.asarray(weights), kind='stable')
+    return np.sort(order[rank::world])
+
+
+def gather_records(local_records, n_total, rank, world, owner_of=None, device=None, group=None):
+    """Gather per-rank result records to rank 0.
+
+    ``local_records``: RESULT_DTYPE array (host) or a uint8 torch tensor of 32*n_local bytes that may
+    live on the GPU.  Returns, on rank 0, a RESULT_DTYPE array of ``n_total`` records in global pair
+    order (``owner_of(rank)`` gives the global indices a rank owns; default round-robin); None elsewhere.
+    """
+    import torch
+    import torch.distributed as dist
+    if owner_of is None:
+        def owner_of(r):
+            return np.arange(r, n_total, world)
+    counts = [len(owner_of(r)) for r in range(world)]
+    cap = max(counts + [1])
+    if isinstance(local_records, np.ndarray):
+        t = torch.from_numpy(local_records.view(np.uint8).reshape(-1).copy())
+        if device is not None:
+            t = t.to(device)
+    else:
+        t = local_records.reshape(-1)
+    pad = torch.zeros(cap * 32, dtype=torch.uint8, device=t.device)
+    pad[:t.numel()] = t
+    if world == 1:
+        chunks = [pad]
+    else:
+        # a true gather: rank r -> rank 0 only (RCCL implements it as grouped send/recv over each rank's
+        # direct xGMI link to the root; gloo has it natively)
+        chunks = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, chunks, dst=0, group=group)
+    if rank != 0:
+        return None
+    full = np.zeros(n_total, RESULT_DTYPE)
+    for r in range(world):
+        rec = chunks[r].cpu().numpy()[:counts[r] * 32].view(RESULT_DTYPE)
+        full[owner_of(r)] = rec
+    return full
+
+
+def gather_bytes(local_bytes, rank, world, group=None):
+    """Gather one ragged uint8 tensor per rank to rank 0 (transcripts): sizes first, then padded
+    payloads.  Returns the list of per-rank tensors on rank 0, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    n = torch.tensor([local_bytes.numel()], dtype=torch.int64, device=local_bytes.device)
+    if world == 1:
+        return [local_bytes]
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    cap = max(int(s.item()) for s in sizes)
+    pad = torch.zeros(max(cap, 1), dtype=torch.uint8, device=local_bytes.device)
+    pad[:local_bytes.numel()] = local_bytes
+    chunks = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, chunks, dst=0, group=group)
+    if rank != 0:
+        return None
+    return [chunks[r][:int(sizes[r].item())] for r in range(world)]

@@ -54,6 +54,7 @@ typedef struct {
 #define PW_ST_TRACED 1  /* traceback ran for this pair */
 #define PW_ST_EMPTY 2   /* empty transcript: the reference's dptable_traceback returns NULL (pw.c:135-138) */
 #define PW_ST_PANICK 4  /* the reference would exit(1) here (pw.c:132-134) */
+#define PW_ST_BADPATH 8 /* internal error: the traceback left the table (never expected) */
 
 /* flags of pw_batch_create */
 #define PW_FLAG_DUMP_SCORES 1   /* also write the score of every cell (for table_scores-style callers) */

@@ -1,0 +1,108 @@
+"""The C-ABI boundary without a GPU: the shared object loads, exports every symbol the headers
+declare, the struct layouts match the reference's, and dptable_init (pure host arithmetic) agrees
+with the reference on dimensions, band clamp and feasibility."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from biseqt_amd import _pwlib as W
+from tests.helpers import dec, kw_of, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, 'include', header)).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    txt = re.sub(r'//[^\n]*', '', txt)
+    return set(re.findall(r'\b(dptable_\w+|pw_\w+)\s*\(', txt)) - {'pw_batch'}
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = W.load()
+    declared = _declared_functions('pwlib.h') | _declared_functions('pw_batch.h')
+    assert {'dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free'} <= declared
+    assert declared == set(W.EXPORTS), declared ^ set(W.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layouts_match_reference_abi():
+    W.check_layout()     # sizeof list measured on the reference
+    assert W.alnchoice.score.offset == 8 and W.alnchoice.base.offset == 16
+    assert W.alnprob.mode.offset == 20 and W.alnprob.params.offset == 24
+    assert W.dptable.row_lens.offset == 16 and W.dptable.prob.offset == 24
+    assert W.alignment.transcript.offset == 16
+
+
+def test_header_is_cdef_clean():
+    """pw.py:61-66 feeds the header to cffi after dropping only lines that START with '#define'."""
+    lines = open(os.path.join(ROOT, 'include', 'pwlib.h')).read().split('\n')
+    kept = [l for l in lines if not l.startswith('#define')]
+    assert not any(l.lstrip().startswith('#') for l in kept)
+
+
+def test_enum_values_match_reference():
+    assert (W.STD_MODE, W.BANDED_MODE) == (0, 1)
+    assert [W.GLOBAL, W.LOCAL, W.START_ANCHORED, W.END_ANCHORED, W.OVERLAP,
+            W.START_ANCHORED_OVERLAP, W.END_ANCHORED_OVERLAP] == list(range(7))
+    assert [W.B_GLOBAL, W.B_LOCAL, W.B_OVERLAP] == [0, 1, 2]
+
+
+def test_dptable_init_matches_reference(capfd):
+    """init rc, clamped band (written back into the caller's struct), num_rows and row_lens for the
+    golden problems -- dptable_init does no GPU work."""
+    from oracle import ref_driver as R
+    lib = R.load(W.PWLIB_SO)           # the same ctypes driver that drives the compiled reference
+    recs = load_golden('random_matrix.json.gz')
+    n = 0
+    for k in range(0, len(recs), 3):
+        rec = recs[k]
+        kw = kw_of(rec)
+        P = R.Problem(dec(rec['origin']), dec(rec['mutant']), **kw)
+        rc = lib.dptable_init(C.byref(P.table))
+        exp = rec['expect']
+        assert rc == exp['init_rc'], (k, rc, exp)
+        if kw['mode'] == 1:
+            assert [P.params.dmin, P.params.dmax] == exp['band'], k
+        if rc == 0:
+            assert P.table.num_rows == exp['num_rows'], k
+            X = P.frame.origin_range.j - P.frame.origin_range.i
+            Y = P.frame.mutant_range.j - P.frame.mutant_range.i
+            for i in range(P.table.num_rows):
+                d = P.params.dmin + i if kw['mode'] == 1 else 0
+                want = Y + 1 if kw['mode'] == 0 else 1 + min(d, 0) + min(X - d, Y)
+                assert P.table.row_lens[i] == want
+                if P.table.row_lens[i] > 0:
+                    assert P.table.cells[i][0].num_choices == 0       # all cells start empty
+            lib.dptable_free(C.byref(P.table))
+            assert not P.table.cells
+            n += 1
+    assert n > 300
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()
+
+
+def test_unsupported_problems_fail_loudly(capfd):
+    from oracle import ref_driver as R
+    lib = R.load(W.PWLIB_SO)
+    P = R.Problem([0, 1, 2], [0, 1], L=4, max_new_mins=3)
+    assert lib.dptable_init(C.byref(P.table)) == -1
+    P = R.Problem([0] * 3000, [0] * 3000, L=4)      # 6001 diagonals > widest kernel: refused, no CPU fallback
+    assert lib.dptable_init(C.byref(P.table)) == -1
+    C.CDLL(None).fflush(None)
+    err = capfd.readouterr().err
+    assert 'max_new_mins' in err and 'no CPU fallback' in err
+
+
+def test_product_does_not_import_the_oracle():
+    """The product path must never route through oracle/ (or the emulator)."""
+    pkg = os.path.join(ROOT, 'biseqt_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.h', '.hip')):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert 'import oracle' not in txt and 'from oracle' not in txt, f
+                assert 'pw_oracle' not in txt and 'emu_wave' not in txt, f

@@ -1,0 +1,80 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` run of the round-robin shard + result gather
+(biseqt_amd/distributed.py).  The per-rank "device results" are produced by the oracle here (no GPU
+in this container); what is under test is the partitioning, padding, gather and re-ordering."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from biseqt_amd import synth
+from biseqt_amd.batch import RESULT_DTYPE
+from biseqt_amd.distributed import shard_indices
+
+
+def test_shard_indices_partition_and_balance():
+    n, world = 103, 8
+    parts = [shard_indices(n, r, world) for r in range(world)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+    assert [p.tolist() for p in parts][3][:3] == [3, 11, 19]                 # pair p -> rank p mod world
+    w = np.random.default_rng(0).integers(1, 1000, n)
+    parts = [shard_indices(n, r, world, weights=w) for r in range(world)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+    loads = [w[p].sum() for p in parts]
+    assert max(loads) - min(loads) <= w.max()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_pairs, tmpdir):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from biseqt_amd.distributed import gather_bytes, gather_records
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    origins, mutants = synth.pair_batch(11, n_pairs, 60)
+    mine = shard_indices(n_pairs, rank, world)
+    rec = np.zeros(len(mine), RESULT_DTYPE)
+    txs = []
+    for k, p in enumerate(mine):
+        r = O.solve(origins[p], mutants[p], L=4, mode=1, alntype=O.B_LOCAL, diag_range=(-10, 10),
+                    match=1, mismatch=-3, go=-5, ge=-2)
+        rec[k] = (r['score'], r['opt'][0], r['opt'][1], r['origin_idx'], r['mutant_idx'],
+                  len(r['transcript']), 1)
+        txs.append(r['transcript'])
+    full = gather_records(rec, n_pairs, rank, world)
+    blob = torch.from_numpy(np.frombuffer(''.join(txs).encode(), dtype=np.uint8).copy())
+    blobs = gather_bytes(blob, rank, world)
+    if rank == 0:
+        np.save(os.path.join(tmpdir, 'full.npy'), full)
+        with open(os.path.join(tmpdir, 'tx.txt'), 'w') as f:
+            f.write('\n'.join(bytes(b.numpy()).decode() for b in blobs))
+    else:
+        assert full is None and blobs is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    n_pairs, world = 9, 2          # odd on purpose: ranks hold 5 and 4 pairs (ragged gather)
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    full = np.load(os.path.join(str(tmp_path), 'full.npy'))
+    origins, mutants = synth.pair_batch(11, n_pairs, 60)
+    txcat = {0: '', 1: ''}
+    for p in range(n_pairs):
+        r = oracle.solve(origins[p], mutants[p], L=4, mode=1, alntype=oracle.B_LOCAL, diag_range=(-10, 10),
+                         match=1, mismatch=-3, go=-5, ge=-2)
+        assert full['score'][p] == r['score'] and (full['opt_i'][p], full['opt_j'][p]) == r['opt'], p
+        assert full['tx_len'][p] == len(r['transcript'])
+        txcat[p % world] += r['transcript']
+    got = open(os.path.join(str(tmp_path), 'tx.txt')).read().split('\n')
+    assert got == [txcat[0], txcat[1]]

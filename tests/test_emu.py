@@ -1,0 +1,86 @@
+"""The kernel's lane program (biseqt_amd/csrc/pw_wave.h) and host planner (pw_plan.h), executed by the
+64-fiber CPU emulator of tests/emu, against the golden vectors and the oracle.  This is the CPU-side
+check of the device logic: same source, lockstep lanes, emulated DPP shifts."""
+import numpy as np
+import pytest
+
+from tests.emu import emu
+from tests.helpers import check_against_expect, dec, kw_of, load_golden
+
+
+def _frame_lens(rec, kw):
+    X = (kw['origin_range'][1] - kw['origin_range'][0]) if 'origin_range' in kw else len(rec['origin'])
+    Y = (kw['mutant_range'][1] - kw['mutant_range'][0]) if 'mutant_range' in kw else len(rec['mutant'])
+    return X, Y
+
+
+def _pick_bk(rec, kw, minimum=2):
+    X, Y = _frame_lens(rec, kw)
+    nd = X + Y + 1 if kw['mode'] == 0 else min(kw['diag_range'][1], X) - max(kw['diag_range'][0], -Y) + 1
+    for bk in (2, 4, 8, 16, 32):
+        if bk >= minimum and 64 * bk >= nd:
+            return bk
+    return None
+
+
+def test_emu_known_answers():
+    for k, rec in enumerate(load_golden('known_answers.json')):
+        kw = kw_of(rec)
+        if len(rec['origin']) > 5000:
+            continue                     # the 2e4 memory case is for the GPU
+        got = emu.solve(dec(rec['origin']), dec(rec['mutant']), bk=_pick_bk(rec, kw), **kw)
+        check_against_expect(got, rec['expect'], where='known[%d]' % k)
+
+
+@pytest.mark.parametrize('variant', ['i32', 'f64', 'generic'])
+def test_emu_random_matrix(variant):
+    recs = load_golden('random_matrix.json.gz')
+    step = {'i32': 7, 'f64': 13, 'generic': 11}[variant]
+    ekw = {'i32': {}, 'f64': dict(use_double=True), 'generic': dict(force_generic=True)}[variant]
+    n = 0
+    for k in range(0, len(recs), step):
+        rec = recs[k]
+        kw = kw_of(rec)
+        minimum = (2, 4, 8, 16, 32)[k % 5] if k % 3 == 0 else 2
+        bk = _pick_bk(rec, kw, minimum)
+        got = emu.solve(dec(rec['origin']), dec(rec['mutant']), bk=bk, **ekw, **kw)
+        check_against_expect(got, rec['expect'], where='random[%d] %s bk=%d' % (k, variant, bk))
+        n += 1
+    assert n > 100
+
+
+def test_emu_float_logodds():
+    recs = load_golden('float_logodds.json')
+    for k in range(0, len(recs), 4):
+        rec = recs[k]
+        kw = kw_of(rec)
+        got = emu.solve(dec(rec['origin']), dec(rec['mutant']), bk=_pick_bk(rec, kw), use_double=True, **kw)
+        check_against_expect(got, rec['expect'], where='float[%d]' % k)
+
+
+def test_emu_steady_phase_and_score_plane(oracle):
+    """Longer problems so that the unpredicated steady-phase body runs; the score-plane dump of the
+    generic kernel against the oracle's table."""
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        n = int(rng.integers(150, 400))
+        o = rng.integers(0, 4, n)
+        m = o.copy()
+        m[rng.random(n) < 0.1] = rng.integers(0, 4, int((rng.random(n) < 0.1).sum() or 1))[0]
+        m = np.delete(m, rng.integers(0, n, 5))
+        kw = dict(L=4, mode=1, alntype=int(rng.integers(0, 3)), diag_range=(-int(rng.integers(6, 40)), int(rng.integers(6, 40))),
+                  match=1., mismatch=-3., go=[-5., 0., -1.][trial % 3], ge=-2.)
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=2, **kw)
+        for key in ('opt', 'score', 'transcript', 'origin_idx', 'mutant_idx'):
+            assert a[key] == b[key], (trial, key)
+    o = rng.integers(0, 4, 40)
+    m = rng.integers(0, 4, 33)
+    kw = dict(L=4, mode=0, alntype=1, match=2., mismatch=-1., go=-2., ge=-1.)
+    a = oracle.solve(o, m, want_table=True, **kw)
+    b = emu.solve(o, m, bk=2, want_table=True, **kw)
+    H = a['H'].reshape(41, 34)
+    plane = b['hdump'].reshape(40 + 33 + 1, 34)
+    for x in range(41):
+        for y in range(34):
+            assert plane[x - y + 33, min(x, y)] == H[x, y], (x, y)

@@ -1,0 +1,313 @@
+"""Parity of the HIP path (through the C ABI of pwlib.so) with the reference: the golden vectors
+generated from the compiled reference, the oracle on seeded random inputs, and size-independent
+properties at BASELINE config sizes.  Bit-exact for integer scores; for the floating-point log-odds
+scores the comparison is also exact (same IEEE double additions in the same association), which is
+stricter than the 3-decimals the reference's own tests ask for (tests/test_pw.py:126-135)."""
+import collections
+import json
+
+import numpy as np
+import pytest
+
+from tests.helpers import check_against_expect, dec, kw_of, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native():
+    """The round-end harness records which .so files were loaded: make sure ours is."""
+    return any('pwlib/pwlib.so' in l for l in open('/proc/self/maps'))
+
+
+def _frames(rec, kw):
+    o, m = dec(rec['origin']), dec(rec['mutant'])
+    orr = kw.get('origin_range', (0, len(o)))
+    mrr = kw.get('mutant_range', (0, len(m)))
+    return o[orr[0]:orr[1]], m[mrr[0]:mrr[1]], orr, mrr
+
+
+def _group_key(kw):
+    return json.dumps([kw['mode'], kw['alntype'], kw['L'], kw.get('subst'), kw.get('match'),
+                       kw.get('mismatch'), kw['go'], kw['ge']])
+
+
+def _run_group(recs_kws, flags=0):
+    """Run golden records that share scoring/type as ONE batch; yields (index, got-dict)."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd.batch import BatchAligner
+    kw0 = recs_kws[0][2]
+    pairs, drs, meta = [], [], []
+    for idx, rec, kw in recs_kws:
+        o, m, orr, mrr = _frames(rec, kw)
+        pairs.append((np.array(o, np.uint8), np.array(m, np.uint8)))
+        drs.append(tuple(kw.get('diag_range', (0, 0))))
+        meta.append((idx, orr, mrr))
+    bkw = dict(alnmode=kw0['mode'], alntype=kw0['alntype'], alphabet_len=kw0['L'], go_score=kw0['go'],
+               ge_score=kw0['ge'], flags=flags)
+    if kw0.get('subst') is not None:
+        bkw['subst_scores'] = kw0['subst']
+    else:
+        bkw['match_score'], bkw['mismatch_score'] = kw0['match'], kw0['mismatch']
+    # golden bands include out-of-table ones (clamped / rejected by the C side like dptable_init):
+    # skip the Python-side assertion of pw.py:224-226
+    if kw0['mode'] == 1:
+        bkw['diag_range'] = drs
+    b = BatchAligner(pairs, check_band=False, **bkw)
+    with b:
+        res = b.run()
+        txs = b.transcripts(res)
+        for k, (idx, orr, mrr) in enumerate(meta):
+            got = dict(init_rc=b.init_rc(k), opt=None, score=None, transcript=None, origin_idx=None,
+                       mutant_idx=None, tb_null=None, would_panick=None)
+            if kw0['mode'] == 1:
+                dmin, dmax, nrows = b.band(k)
+                got['band'] = (dmin, dmax)
+            if got['init_rc'] == 0:
+                got['num_rows'] = b.band(k)[2]
+                got['opt'] = (int(res['opt_i'][k]), int(res['opt_j'][k]))
+                if got['opt'][0] != -1:
+                    st = int(res['status'][k])
+                    assert st & W.PW_ST_TRACED
+                    got['score'] = float(res['score'][k])
+                    got['would_panick'] = bool(st & W.PW_ST_PANICK)
+                    got['tb_null'] = bool(st & W.PW_ST_EMPTY) and not (st & W.PW_ST_PANICK)
+                    if not (st & (W.PW_ST_PANICK | W.PW_ST_EMPTY)):
+                        got['transcript'] = txs[k]
+                        got['origin_idx'] = int(res['origin_idx'][k]) + orr[0]
+                        got['mutant_idx'] = int(res['mutant_idx'][k]) + mrr[0]
+            yield idx, got
+
+
+def _check_file(name, flags=0, every=1):
+    recs = load_golden(name)
+    groups = collections.OrderedDict()
+    for idx in range(0, len(recs), every):
+        kw = kw_of(recs[idx])
+        groups.setdefault(_group_key(kw), []).append((idx, recs[idx], kw))
+    n = 0
+    for key, items in groups.items():
+        for idx, got in _run_group(items, flags):
+            check_against_expect(got, recs[idx]['expect'], where='%s[%d]' % (name, idx))
+            n += 1
+    assert _loaded_native()
+    return n
+
+
+def test_known_answers_batch():
+    assert _check_file('known_answers.json') == 17
+
+
+def test_random_matrix_batch_int32():
+    assert _check_file('random_matrix.json.gz') == 3000
+
+
+def test_random_matrix_batch_f64_and_generic():
+    from biseqt_amd import _pwlib as W
+    _check_file('random_matrix.json.gz', flags=W.PW_FLAG_FORCE_F64, every=2)
+    _check_file('random_matrix.json.gz', flags=W.PW_FLAG_FORCE_GENERIC, every=3)
+    _check_file('random_matrix.json.gz', flags=W.PW_FLAG_FORCE_GENERIC | W.PW_FLAG_FORCE_F64, every=5)
+
+
+def test_float_logodds_batch():
+    assert _check_file('float_logodds.json') == 90
+
+
+def test_config_sized_batch():
+    assert _check_file('config_sized.json') == 16
+
+
+# ---- the reference's own caller-level tests (tests/test_pw.py) through Aligner -------------------
+@pytest.mark.parametrize('letters', ['ACGT', ['00', '01']], ids=['one letter alphabet', 'two letter alphabet'])
+def test_alignment_std_basic(letters):
+    from biseqt_amd.pw import Aligner, Alignment, LOCAL, OVERLAP
+    from biseqt_amd.sequence import Alphabet
+    alphabet = Alphabet(letters)
+    S = alphabet.parse(alphabet[0] * 10)
+    with Aligner(S, S) as aligner:
+        aligner.solve()
+        assert aligner.traceback().transcript == 'M' * len(S)
+        scores = aligner.table_scores()
+        assert len(scores) == len(S) and all(len(row) == len(S) for row in scores)
+        assert max(max(row) for row in scores) == scores[-1][-1]
+    with Aligner(S, S[:len(S) // 2]) as aligner:
+        aligner.solve()
+        alignment = aligner.traceback()
+        assert alignment.transcript.count('D') == len(S) // 2
+        assert '-' * (len(S) // 2) in str(alignment)
+    junk = alphabet.parse(alphabet[1] * len(S))
+    origin, mutant = S + junk, junk + S
+    alignment = Alignment(origin, mutant, 'M' * len(S), mutant_start=len(S))
+    with Aligner(origin, mutant, alntype=LOCAL) as aligner:
+        aligner.solve()
+        assert alignment == aligner.traceback()
+    with Aligner(S, junk, alntype=LOCAL) as aligner:
+        assert aligner.solve() is None and aligner.traceback() is None
+    with Aligner(origin, mutant, alntype=OVERLAP) as aligner:
+        aligner.solve()
+        assert aligner.traceback().transcript == 'M' * len(S)
+
+
+@pytest.mark.parametrize('letters', ['ACGT', ['00', '01']], ids=['one letter alphabet', 'two letter alphabet'])
+def test_alignment_banded_basic(letters):
+    from biseqt_amd.pw import Aligner, Alignment, BANDED_MODE, B_OVERLAP
+    from biseqt_amd.sequence import Alphabet
+    alphabet = Alphabet(letters)
+    S = alphabet.parse(alphabet[0] * 10)
+    with Aligner(S, S, alnmode=BANDED_MODE, diag_range=(0, 0)) as aligner:
+        aligner.solve()
+        assert aligner.traceback() == Alignment(S, S, 'M' * len(S))
+    junk = alphabet.parse(alphabet[1] * len(S))
+    origin, mutant = S + junk, junk + S
+    alignment = Alignment(origin, mutant, 'M' * len(S), mutant_start=len(S))
+    with Aligner(origin, mutant, alnmode=BANDED_MODE, alntype=B_OVERLAP,
+                 diag_range=(-2 * len(S), 2 * len(S)), ge_score=-1) as aligner:
+        aligner.solve()
+        assert alignment == aligner.traceback()
+
+
+def test_alignment_banded_memory():
+    """tests/test_pw.py:95-103 at full size: 1e6 x 1e6, band (0,0)."""
+    from biseqt_amd.pw import Aligner, BANDED_MODE
+    from biseqt_amd.sequence import Alphabet, Sequence
+    A = Alphabet('ACGT')
+    L = int(1e6)
+    S, T = Sequence(A, (0,) * L), Sequence(A, (1,) * L)
+    with Aligner(S, T, alnmode=BANDED_MODE, diag_range=(0, 0)) as aligner:
+        aligner.solve()
+        assert aligner.traceback().transcript == 'S' * L
+
+
+@pytest.mark.parametrize('err', [1e-2, 1e-1, 2e-1, 3e-1, 4e-1])
+@pytest.mark.parametrize('local', [False, True])
+def test_alignment_log_odds_properties(err, local):
+    """tests/test_pw.py:106-140 and :157-185 (float log-odds scores, 3-decimal tolerance as there)."""
+    from biseqt_amd.pw import Aligner, Alignment, STD_MODE, GLOBAL, LOCAL
+    from biseqt_amd.sequence import Alphabet
+    from biseqt_amd.stochastics import MutationProcess, rand_seq
+    rng = np.random.default_rng(int(err * 1000) + local)
+    A = Alphabet('ACGT')
+    M = MutationProcess(A, subst_probs=err, go_prob=err, ge_prob=err, rng=rng)
+    subst_scores, (go_score, ge_score) = M.log_odds_scores()
+    S = rand_seq(A, 100, rng=rng)
+    T, tx = M.mutate(S)
+    if local:
+        T = A.parse('A' * 100) + T + A.parse('G' * 100)
+        mutation_aln = Alignment(S, T, tx, mutant_start=100)
+    else:
+        mutation_aln = Alignment(S, T, tx)
+    mutation_score = mutation_aln.calculate_score(subst_scores, go_score, ge_score)
+    with Aligner(S, T, subst_scores=subst_scores, go_score=go_score, ge_score=ge_score,
+                 alnmode=STD_MODE, alntype=LOCAL if local else GLOBAL) as aligner:
+        reported_score = aligner.solve()
+        assert round(reported_score, 3) >= round(mutation_score, 3)
+        alignment = aligner.traceback()
+        aln_score = alignment.calculate_score(subst_scores, go_score, ge_score)
+        assert round(aln_score, 3) == round(reported_score, 3)
+        assert round(aln_score, 3) == round(aligner.calculate_score(alignment), 3)
+        ori_len = Alignment.projected_len(alignment.transcript, on='origin')
+        mut_len = Alignment.projected_len(alignment.transcript, on='mutant')
+        if local:
+            assert ori_len <= len(S) and mut_len < len(T)
+        else:
+            assert ori_len == len(S) and mut_len == len(T)
+
+
+def test_table_scores_match_oracle(oracle):
+    from biseqt_amd.pw import Aligner, LOCAL
+    from biseqt_amd.sequence import Alphabet, Sequence
+    rng = np.random.default_rng(9)
+    A = Alphabet('ACGT')
+    o, m = rng.integers(0, 4, 70).tolist(), rng.integers(0, 4, 55).tolist()
+    with Aligner(Sequence(A, o), Sequence(A, m), alntype=LOCAL, match_score=2, mismatch_score=-1,
+                 go_score=-2, ge_score=-1) as aligner:
+        score = aligner.solve()
+        table = aligner.table_scores()
+    ref = oracle.solve(o, m, L=4, alntype=oracle.LOCAL, match=2, mismatch=-1, go=-2, ge=-1, want_table=True)
+    assert score == ref['score']
+    H = ref['H'].reshape(71, 56)
+    assert np.array_equal(np.array(table), H[:70, :55])
+
+
+# ---- seeded random batches against the oracle, and properties at BASELINE sizes ------------------
+def test_random_batch_against_oracle(oracle):
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    origins, mutants = synth.pair_batch(42, 96, 600)
+    pairs = list(zip(origins, mutants))
+    sc = dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
+    for mode, typ, dr in ((1, 1, (-60, 60)), (1, 2, (-100, 40)), (0, 1, None), (0, 0, None)):
+        kw = dict(alnmode=mode, alntype=typ, alphabet_len=4, **sc)
+        if dr:
+            kw['diag_range'] = dr
+        with BatchAligner(pairs, **kw) as b:
+            res = b.run()
+            txs = b.transcripts(res)
+        for k in range(0, len(pairs), 5):
+            r = oracle.solve(origins[k], mutants[k], L=4, mode=mode, alntype=typ, diag_range=dr,
+                             match=1, mismatch=-3, go=-5, ge=-2)
+            assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (mode, typ, k)
+            assert res['score'][k] == r['score']
+            assert txs[k] == r['transcript']
+            assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def _rescore(o, m, tx, i, j, match, mismatch, go, ge):
+    s, prev = 0, ''
+    for op in tx:
+        if op in 'MS':
+            s += match if o[i] == m[j] else mismatch
+            assert (o[i] == m[j]) == (op == 'M')
+            i, j = i + 1, j + 1
+        else:
+            s += ge + (go if op != prev else 0)
+            if op == 'D':
+                i += 1
+            else:
+                j += 1
+        prev = op
+    return s, i, j
+
+
+def test_config2_properties_full_size(oracle):
+    """BASELINE config 2 shape (2 kb x 2 kb, band radius 200, B_LOCAL, 1/-3/-5/-2) on 512 pairs:
+    re-scoring every transcript reproduces its score, the path stays inside the band and ends at the
+    reported end cell; a sample is compared with the oracle cell for cell."""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    n = 512
+    origins, mutants = synth.pair_batch(2, n, 2000)
+    with BatchAligner(list(zip(origins, mutants)), alnmode=1, alntype=1, alphabet_len=4,
+                      diag_range=(-200, 200), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as b:
+        assert b.score_dtype == 'i32'
+        cells = b.cells
+        res = b.run()
+        txs = b.transcripts(res)
+    assert cells == sum(synth.banded_cells(len(o), len(m), -200, 200) for o, m in zip(origins, mutants))
+    for k in range(n):
+        o, m = origins[k], mutants[k]
+        s, i, j = _rescore(o, m, txs[k], int(res['origin_idx'][k]), int(res['mutant_idx'][k]), 1, -3, -5, -2)
+        assert s == res['score'][k], k
+        d = int(res['opt_i'][k]) - 200          # band not clamped at this size: dmin = -200
+        a = int(res['opt_j'][k])
+        assert (i, j) == (a + max(d, 0), a - min(d, 0)), k
+    for k in range(0, n, 64):
+        r = oracle.solve(origins[k], mutants[k], L=4, mode=1, alntype=1, diag_range=(-200, 200),
+                         match=1, mismatch=-3, go=-5, ge=-2)
+        assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score']
+        assert txs[k] == r['transcript']
+
+
+def test_traceback_from_explicit_end_cells(oracle):
+    """dptable_traceback accepts any end cell (pw.c:116-123), not only the optimum."""
+    from biseqt_amd.batch import BatchAligner
+    rng = np.random.default_rng(17)
+    o, m = rng.integers(0, 4, 50), rng.integers(0, 4, 47)
+    with BatchAligner([(o, m)], alnmode=0, alntype=0, alphabet_len=4, match_score=1, mismatch_score=-1,
+                      go_score=-1, ge_score=-1) as b:
+        b.solve()
+        b.traceback_from([[30, 28]])
+        b.sync()
+        res = b.results()
+        tx = b.transcripts(res)[0]
+    r = oracle.solve(o[:30], m[:28], L=4, match=1, mismatch=-1, go=-1, ge=-1)   # global: prefix problem
+    assert tx == r['transcript']
