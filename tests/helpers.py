@@ -25,6 +25,11 @@ def kw_of(rec):
     for k in ('origin_range', 'mutant_range', 'diag_range'):
         if k in kw:
             kw[k] = tuple(kw[k])
+    kw.setdefault('go', 0.)
+    kw.setdefault('ge', 0.)
+    if kw.get('subst') is None:
+        kw.setdefault('match', 1.)       # the reference's defaults (pw.py:185-195)
+        kw.setdefault('mismatch', 0.)
     if 'kw_hex' in rec:      # exact float scores
         kw['subst'] = [[float.fromhex(v) for v in row] for row in rec['kw_hex']['subst']]
         kw['go'] = float.fromhex(rec['kw_hex']['go'])
