@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-PWLIB_SO = os.path.join(HERE, 'pwlib', 'pwlib.so')
+PWLIB_SO = os.environ.get('PWLIB_SO', os.path.join(HERE, 'pwlib', 'pwlib.so'))   # override: A/B experiments only
 PWLIB_H = os.path.join(HERE, 'pwlib', 'pwlib.h')
 
 # enum values of include/pwlib.h (reference pwlib.h:30-33, 39-54, 60-65)

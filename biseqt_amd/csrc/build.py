@@ -16,13 +16,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT_DIR = os.path.join(os.path.dirname(HERE), 'pwlib')
-OBJ_DIR = os.path.join(HERE, '_build')
-SO = os.path.join(OUT_DIR, 'pwlib.so')
+OBJ_DIR = os.path.join(HERE, os.environ.get('PW_OBJ_DIR', '_build'))
+SO = os.path.join(OUT_DIR, os.environ.get('PW_SO_NAME', 'pwlib.so'))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 # -ffp-contract=off: the f64 path must add exactly as the reference does, (H + ge) + go, no FMA
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
-          '-Wno-unused-function']
+          '-Wno-unused-function'] + os.environ.get('PW_EXTRA_CXXFLAGS', '').split()
 BKS = (2, 4, 8, 16, 32)
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']

@@ -33,8 +33,11 @@ struct DevP {
 
 constexpr int kMaxLdsL = 32;   // substitution tables up to 32 x 32 are staged in LDS
 
+#ifndef PW_FILL_ATTR
+#define PW_FILL_ATTR
+#endif
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
-__global__ __launch_bounds__(64) void k_fill(const FillParams<T> a) {
+__global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a) {
   __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
   const T* tab = a.subst;
   if (GENERIC) {

@@ -6,12 +6,43 @@ namespace pw {
 
 __global__ __launch_bounds__(64) void k_trace(const TraceParams p) {
   const int pair = (int)(blockIdx.x * 64u + threadIdx.x);
-  if (pair < p.npairs) trace_pair(p, pair);
+  if (pair < p.npairs) trace_walk(p, pair);
+}
+
+// K4b, wave-parallel: one wavefront per pair, 64 transcript positions per pass.  The (x, y) each
+// position refers to is the start cell plus the number of origin- / mutant-consuming ops in front of it:
+// a ballot and a popcount below the lane.
+__global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
+  const int pair = (int)blockIdx.x;
+  const PairDesc& pd = p.pairs[pair];
+  if (!pd.solvable) return;
+  const Result r = p.results[pair];
+  if (!(r.status & ST_TRACED) || r.tx_len <= 0) return;
+  const uint8_t* oseq = p.arena + pd.o_off;
+  const uint8_t* mseq = p.arena + pd.m_off;
+  uint8_t* tx = p.transcripts + pd.tx_off + pd.tx_cap - r.tx_len;
+  const int lane = (int)(threadIdx.x & 63u);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int x = r.origin_idx, y = r.mutant_idx;
+  for (int k0 = 0; k0 < r.tx_len; k0 += 64) {
+    const int k = k0 + lane;
+    const uint8_t ch = k < r.tx_len ? tx[k] : (uint8_t)0;
+    const bool isx = ch == 'X';
+    const unsigned long long bo = __ballot(isx || ch == 'D'), bm = __ballot(isx || ch == 'I');
+    if (isx) {
+      const int mx = x + __popcll(bo & below), my = y + __popcll(bm & below);
+      tx[k] = (oseq[mx] == mseq[my]) ? 'M' : 'S';
+    }
+    x += __popcll(bo); y += __popcll(bm);
+  }
 }
 
 hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
   if (p.npairs <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_trace, dim3((unsigned)((p.npairs + 63) / 64)), dim3(64), 0, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_trace_fixup, dim3((unsigned)p.npairs), dim3(64), 0, st, p);
   return hipGetLastError();
 }
 

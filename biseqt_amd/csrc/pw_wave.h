@@ -119,6 +119,8 @@ struct WaveFill {
     return oc == mc ? a.match : a.mismatch;
   }
 
+  PW_FN static uint32_t umin1(uint32_t v) { return v < 1u ? v : 1u; }
+
   // One cell of slot J on step t (lane-local coordinates x, y).
   template <bool RAMP, int J>
   PW_FN void cell(T up, T left, uint32_t oc, uint32_t mc, int x, int y, int t) {
@@ -149,6 +151,26 @@ struct WaveFill {
       Hn = hI > Hn ? hI : Hn;
       Hn = hM > Hn ? hM : Hn;
     }
+#if defined(PW_ARITH_SELECT)
+    if (Tr::is_int && !GENERIC && !RAMP && BANY) {
+      // tie bits as 0/1 integers computed in the vector ALU only (no compare -> SGPR -> select round trip
+      // on the recurrence's critical path): n* = min(Hn - cand, 1) is 0 iff the candidate is kept
+      const uint32_t nD = umin1((uint32_t)(Hn - hD)), nI = umin1((uint32_t)(Hn - hI));
+      const uint32_t nM = umin1((uint32_t)(Hn - hM)), nB = umin1((uint32_t)Hn);
+      const T Hgb = Hn + a.ge + blkL[J];
+      U[J] = Hgb + (T)nD * a.go;
+      L[J] = Hgb + (T)nI * a.go;
+      const uint32_t inv = nB | (nD << 1) | (nI << 2) | (nM << 3);
+      m[J] = (m[J] << 4) | (inv ^ 15u);
+      H[J] = Hn;
+      if (TRACK) {
+        const bool upd = Hn > best[J];
+        best[J] = upd ? Hn : best[J];
+        bestT[J] = upd ? t : bestT[J];
+      }
+      return;
+    }
+#endif
     const bool bB = ball && (Hn == T(0));
     const bool bD = (hD == Hn), bI = (hI == Hn), bM = (hM == Hn);
     // what this cell offers downwards (as a D predecessor) and rightwards (as an I predecessor):
@@ -222,15 +244,14 @@ struct WaveFill {
 
   // One iteration = the even step 2*it and the odd step 2*it + 1.
   template <bool RAMP>
-  PW_FN void iteration(int it) {
+  PW_FN void iteration(int it, int k) {
     // even step: slot 0 takes its "up" offer from the previous lane's last slot
     const T uin = xshr1<P>(U[BK - 1], Tr::neg());
     EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
     // the origin window moves on by one letter: lane l takes lane l+1's lowest letter, the last lane
     // is fed from the arena
     {
-      const int oi = xfeed_o + it;
-      const uint32_t feed = oseq[pw_clampi(oi, 0, olast)];
+      const uint32_t feed = feed_byte(fo_lo, fo_hi, k);
       const uint32_t oin = xshl1<P>(ow[0], feed);
 #pragma unroll
       for (int i = 0; i + 1 < R; i++) ow[i] = ow[i + 1];
@@ -241,8 +262,7 @@ struct WaveFill {
     OddLoop<RAMP, 0>::run(*this, lin, 2 * it + 1);
     // the mutant window moves on: lane l takes lane l-1's highest letter, lane 0 is fed from the arena
     {
-      const int mi = yfeed_m + it;
-      const uint32_t feed = mseq[pw_clampi(mi, 0, mlast)];
+      const uint32_t feed = feed_byte(fm_lo, fm_hi, k);
       const uint32_t min_ = xshr1<P>(mw[R - 1], feed);
 #pragma unroll
       for (int i = R - 1; i > 0; i--) mw[i] = mw[i - 1];
@@ -251,7 +271,35 @@ struct WaveFill {
     xbase++; ybase++;
   }
 
-  int xfeed_o, yfeed_m;       // uniform: arena index the edge lanes are fed from at iteration 0
+  // ---- edge-lane feeders (wave-uniform) ----------------------------------------------------------
+  // The last lane needs origin letter o[xfeed_o + it] and lane 0 mutant letter m[yfeed_m + it] on
+  // iteration `it`.  The 8 letters a block consumes per sequence are fetched as three aligned dwords ONE
+  // BLOCK AHEAD (feed_issue) and funnel-shifted into two registers when the block starts (feed_commit),
+  // so no iteration ever waits on memory.  Word indices are clamped: letters outside the sequence feed
+  // only cells outside the table.
+  int xfeed_o, yfeed_m;       // arena index the edge lanes are fed from at iteration 0
+  int owlast, mwlast;         // last dword of each frame
+  uint32_t fo_lo, fo_hi, fm_lo, fm_hi;                 // the current block's 8 + 8 letters
+  uint32_t fo_n0, fo_n1, fo_n2, fm_n0, fm_n1, fm_n2;   // next block's raw dwords
+
+  PW_FN static uint32_t feed_byte(uint32_t lo, uint32_t hi, int k) {
+    return ((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xffu;
+  }
+  PW_FN static uint32_t funnel(uint32_t hi, uint32_t lo, int r) {
+    return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> (8 * r));
+  }
+  PW_FN void feed_issue(int b) {
+    const uint32_t* o32 = (const uint32_t*)oseq;
+    const uint32_t* m32 = (const uint32_t*)mseq;
+    const int wo = (xfeed_o + 8 * b) >> 2, wm = (yfeed_m + 8 * b) >> 2;
+    fo_n0 = o32[pw_clampi(wo, 0, owlast)]; fo_n1 = o32[pw_clampi(wo + 1, 0, owlast)]; fo_n2 = o32[pw_clampi(wo + 2, 0, owlast)];
+    fm_n0 = m32[pw_clampi(wm, 0, mwlast)]; fm_n1 = m32[pw_clampi(wm + 1, 0, mwlast)]; fm_n2 = m32[pw_clampi(wm + 2, 0, mwlast)];
+  }
+  PW_FN void feed_commit(int b) {
+    const int ro = (xfeed_o + 8 * b) & 3, rm = (yfeed_m + 8 * b) & 3;
+    fo_lo = funnel(fo_n1, fo_n0, ro); fo_hi = funnel(fo_n2, fo_n1, ro);
+    fm_lo = funnel(fm_n1, fm_n0, rm); fm_hi = funnel(fm_n2, fm_n1, rm);
+  }
 
   // A block = 16 steps = 8 iterations = one mask dword per slot.  The steady body is fully unrolled (the
   // letter-window shifts become register renames); the predicated ramp body runs only at the two ends
@@ -260,10 +308,10 @@ struct WaveFill {
   PW_FN void block(int b) {
     if (RAMP) {
 #pragma unroll 1
-      for (int k = 0; k < 8; k++) iteration<true>(8 * b + k);
+      for (int k = 0; k < 8; k++) iteration<true>(8 * b + k, k);
     } else {
 #pragma unroll
-      for (int k = 0; k < 8; k++) iteration<false>(8 * b + k);
+      for (int k = 0; k < 8; k++) iteration<false>(8 * b + k, k);
     }
   }
 
@@ -280,6 +328,7 @@ struct WaveFill {
     X = pd.X; Y = pd.Y; ndiag = pd.ndiag;
     oseq = a.arena + pd.o_off; mseq = a.arena + pd.m_off;
     olast = X > 0 ? X - 1 : 0; mlast = Y > 0 ? Y - 1 : 0;
+    owlast = olast >> 2; mwlast = mlast >> 2;
     njl = ndiag - lane * BK;
     // s0 == dmin (mod 2): e, f are exact
     const int e = (pd.s0 + pd.dmin) >> 1;       // x of diagonal dd = 0 on step t = 0
@@ -300,7 +349,10 @@ struct WaveFill {
       ow[i] = oseq[pw_clampi(xbase + i - 1, 0, olast)];
       mw[i] = mseq[pw_clampi(ybase - i - 1, 0, mlast)];
     }
+    feed_issue(0);
     for (int b = 0; b < pd.nblocks; b++) {
+      feed_commit(b);
+      if (b + 1 < pd.nblocks) feed_issue(b + 1);
       if (b >= pd.steady_b0 && b < pd.steady_b1) block<false>(b);
       else block<true>(b);
       store_masks(b);
@@ -370,56 +422,104 @@ struct WaveFill {
 // kept in the predecessor else its first kept op; go == 0 -> first kept; go > 0 -> first kept op
 // other than g, else g.  After M/S: first kept (_pw_internals.c:235).
 // =================================================================================================
-PW_FN uint32_t pw_mask_at(const TraceParams& p, const PairDesc& pd, int x, int y) {
-  const int dd = x - y - pd.dmin;
-  const int t = x + y - pd.s0;
-  const int lane = dd / pd.bk, j = dd % pd.bk;
-  const uint32_t w = p.masks[pd.mask_off + mask_word_index(pd.bk, t >> 4, lane, j)];
-  return (w >> (4 * (7 - ((t & 15) >> 1)))) & 15u;
-}
-
 PW_FN int pw_first_op(uint32_t mask) {   // index of the lowest set bit: 0 B, 1 D, 2 I, 3 M
   return (mask & 1u) ? 0 : (mask & 2u) ? 1 : (mask & 4u) ? 2 : 3;
 }
 
-PW_FN void trace_pair(const TraceParams& p, int pair) {
-  const PairDesc& pd = p.pairs[pair];
-  if (!pd.solvable) return;
+struct __attribute__((aligned(8))) U4 { uint32_t x, y, z, w; };
+
+// ---- K4a: the walk --------------------------------------------------------------------------------
+// One lane walks one pair; a wavefront holds 64 walkers.  The walk is a chain of dependent steps, and
+// 64 divergent walkers share one program counter, so ANY lane touching memory stalls all 64.  The loop
+// is therefore split: an outer iteration in which every unfinished lane refills a private register
+// cache with ONE batched access -- the 16-byte mask groups (4 adjacent diagonals) of its current block
+// and of the block before it -- and an inner loop that only steps while the next cell is inside that
+// cache: no loads at all, just byte stores of the ops.  A lane that leaves its cached window idles
+// until the others do; all refill together.  Sequence letters are not read here: diagonal moves are
+// written as 'X' and turned into 'M'/'S' by the fix-up pass (K4b), which is fully parallel.
+PW_FN void trace_walk(const TraceParams& p, int pair) {
+  // everything the loops need is copied into locals first: the byte stores of the ops go through a
+  // uint8_t*, which the compiler must assume aliases the descriptors
+  const PairDesc pdv = p.pairs[pair];
+  if (!pdv.solvable) return;
   Result r = p.results[pair];
   const int ei = p.ends ? p.ends[2 * pair] : r.opt_i;
   const int ej = p.ends ? p.ends[2 * pair + 1] : r.opt_j;
   if (ei < 0 || ej < 0) { r.tx_len = 0; r.status = 0; p.results[pair] = r; return; }
+  const int dmin = pdv.dmin, s0 = pdv.s0, ndiag = pdv.ndiag, bk = pdv.bk, gosign = p.gosign;
   int x = ei, y = ej;
   if (p.banded) {                 // _xy_from_cellpos (_pw_internals.c:100-114)
-    const int d = ei + pd.dmin;
+    const int d = ei + dmin;
     x = ej + (d > 0 ? d : 0); y = ej - (d > 0 ? 0 : d);
   }
-  const uint8_t* oseq = p.arena + pd.o_off;
-  const uint8_t* mseq = p.arena + pd.m_off;
-  uint8_t* tx = p.transcripts + pd.tx_off;
-  int pos = pd.tx_cap;            // ops are written backwards, ending right-aligned in the slot
+  const uint32_t* __restrict__ plane = p.masks + pdv.mask_off;
+  uint8_t* __restrict__ tx = p.transcripts + pdv.tx_off;
+  const int lg = bk == 2 ? 1 : bk == 4 ? 2 : bk == 8 ? 3 : bk == 16 ? 4 : 5;   // log2(bk)
+  const int lgG = bk < 4 ? 1 : 2;               // log2 of the dwords per lane group (pw_types.h: mask_word_index)
+  const int G = 1 << lgG;
+  const int njg = bk >> lgG;
+  int pos = pdv.tx_cap;           // ops are written backwards, ending right-aligned in the slot
   int nms = 0, bad = 0;
-  uint32_t mask = pw_mask_at(p, pd, x, y);
-  int op = pw_first_op(mask);     // choices[0] of the end cell (pw.c:123)
-  while (op != 0 && pos > 0) {
-    uint8_t ch;
-    if (op == 3) { ch = (oseq[x - 1] == mseq[y - 1]) ? 'M' : 'S'; nms++; x--; y--; }
-    else if (op == 1) { ch = 'D'; x--; }
-    else { ch = 'I'; y--; }
-    tx[--pos] = ch;
-    // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
-    // instead of reading out of bounds
-    const int dd = x - y - pd.dmin;
-    if (x < 0 || y < 0 || dd < 0 || dd >= pd.ndiag) { bad = 1; break; }
-    const uint32_t pm = pw_mask_at(p, pd, x, y);
-    if (op == 3 || p.gosign == 0) op = pw_first_op(pm);
-    else if (p.gosign < 0) op = (pm & (1u << op)) ? op : pw_first_op(pm);
-    else { const uint32_t others = pm & ~(1u << op); op = others ? pw_first_op(others) : op; }
+  int prev = 3;                   // op that led to the current cell; "M" makes the end cell use its first choice (pw.c:123)
+  bool done = false;
+  while (!done) {
+    // ---- refill: groups of block cb and cb - 1 around the current cell ----
+    const int dd0 = x - y - dmin, t0 = x + y - s0;
+    if (x < 0 || y < 0 || dd0 < 0 || dd0 >= ndiag) { bad = 1; break; }   // never expected: see below
+    const int cln = dd0 >> lg, cjg = (dd0 & (bk - 1)) >> lgG, cb = t0 >> 4;
+    // two unconditional 16-byte loads issued back to back (for bk = 2 a group is 8 bytes and the upper half
+    // of the load is the neighbouring lane's group: in bounds thanks to the slack behind the mask workspace)
+    const int cbm = cb > 0 ? cb - 1 : 0;
+    const U4 c0 = *(const U4*)(plane + ((uint64_t)((uint64_t)cb * njg + cjg) * 64 + cln) * G);
+    const U4 c1 = *(const U4*)(plane + ((uint64_t)((uint64_t)cbm * njg + cjg) * 64 + cln) * G);
+    // ---- step while the cell is inside the cached window ----
+    while (true) {
+      const int dd = x - y - dmin, t = x + y - s0;
+      // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
+      if (x < 0 || y < 0 || dd < 0 || dd >= ndiag) { bad = 1; done = true; break; }
+      const int ln = dd >> lg, j = dd & (bk - 1), jg = j >> lgG, b = t >> 4;
+      if (ln != cln || jg != cjg || (b != cb && b != cb - 1)) break;          // miss: refill
+      const int q = j & (G - 1);
+      const uint32_t wx = (b == cb) ? c0.x : c1.x, wy = (b == cb) ? c0.y : c1.y;
+      const uint32_t wz = (b == cb) ? c0.z : c1.z, ww = (b == cb) ? c0.w : c1.w;
+      const uint32_t w = q == 0 ? wx : q == 1 ? wy : q == 2 ? wz : ww;
+      const uint32_t pm = (w >> (4 * (7 - ((t & 15) >> 1)))) & 15u;
+      // which kept choice of this cell is the base of the step that led here
+      int op;
+      if (prev == 3 || gosign == 0) op = pw_first_op(pm);
+      else if (gosign < 0) op = (pm & (1u << prev)) ? prev : pw_first_op(pm);
+      else { const uint32_t others = pm & ~(1u << prev); op = others ? pw_first_op(others) : prev; }
+      if (op == 0 || pos <= 0) { done = true; break; }
+      tx[--pos] = op == 3 ? 'X' : (op == 1 ? 'D' : 'I');
+      nms += (op == 3);
+      x -= (op != 2); y -= (op != 1);
+      prev = op;
+    }
   }
   r.origin_idx = x; r.mutant_idx = y;
-  r.tx_len = pd.tx_cap - pos;
+  r.tx_len = pdv.tx_cap - pos;
   r.status = ST_TRACED | (r.tx_len == 0 ? ST_EMPTY : 0) | ((x + y + nms <= 0) ? ST_PANICK : 0) | (bad ? ST_BADPATH : 0);
   p.results[pair] = r;
+}
+
+// ---- K4b: turn the diagonal moves 'X' into 'M' / 'S' (_pw_internals.c:232) ------------------------
+// Serial form (one pair, one thread): what the wave-parallel device version in pw_trace.hip computes
+// with ballots + popcounts; the CPU lane emulator uses this one.
+PW_FN void trace_fixup_serial(const TraceParams& p, int pair) {
+  const PairDesc& pd = p.pairs[pair];
+  if (!pd.solvable) return;
+  const Result r = p.results[pair];
+  if (!(r.status & ST_TRACED) || r.tx_len <= 0) return;
+  const uint8_t* oseq = p.arena + pd.o_off;
+  const uint8_t* mseq = p.arena + pd.m_off;
+  uint8_t* tx = p.transcripts + pd.tx_off + pd.tx_cap - r.tx_len;
+  int x = r.origin_idx, y = r.mutant_idx;
+  for (int k = 0; k < r.tx_len; k++) {
+    const uint8_t ch = tx[k];
+    if (ch == 'X') { tx[k] = (oseq[x] == mseq[y]) ? 'M' : 'S'; x++; y++; }
+    else if (ch == 'D') x++;
+    else y++;
+  }
 }
 
 }  // namespace pw

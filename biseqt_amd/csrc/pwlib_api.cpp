@@ -122,6 +122,7 @@ int batch_build(pw_batch* b) {
     if (p.origin_off + (uint64_t)p.origin_len > b->arena_bytes || p.mutant_off + (uint64_t)p.mutant_len > b->arena_bytes)
       return fail("pair frame outside the arena");
     if ((int64_t)p.origin_len + p.mutant_len > (1 << 30)) return fail("sequences too long");
+    if ((p.origin_off & 3) || (p.mutant_off & 3)) return fail("frames must start on a 4-byte boundary of the arena");
     pw::Plan pl = pw::plan_problem(b->mode, b->type, p.origin_len, p.mutant_len, p.dmin, p.dmax);
     b->plans[k] = pl;
     pw::PairDesc d;
@@ -173,9 +174,9 @@ int batch_build(pw_batch* b) {
   // ---- device buffers ----
   HIP_TRY(hipSetDevice(b->device));
   b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
-  HIP_TRY(hipMalloc((void**)&b->d_arena, std::max<uint64_t>(b->arena_bytes, 16)));
+  HIP_TRY(hipMalloc((void**)&b->d_arena, b->arena_bytes + 16));   // kernels read whole dwords: slack past the last frame
   HIP_TRY(hipMalloc((void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1)));
-  HIP_TRY(hipMalloc((void**)&b->d_masks, 4 * std::max<uint64_t>(mask_words, 4)));
+  HIP_TRY(hipMalloc((void**)&b->d_masks, 4 * mask_words + 64));   // slack: the walker reads whole 16-byte groups
   HIP_TRY(hipMalloc((void**)&b->d_results, sizeof(pw::Result) * std::max<int32_t>(b->n, 1)));
   HIP_TRY(hipMalloc((void**)&b->d_tx, std::max<uint64_t>(tx_bytes, 16)));
   const size_t esz = b->use_f64 ? 8 : 4;
@@ -505,10 +506,11 @@ intpair dptable_solve(dptable* T) {
   const int X = fr->origin_range.j - fr->origin_range.i, Y = fr->mutant_range.j - fr->mutant_range.i;
   if (T->num_rows <= 0) return none;
   // letters -> one byte each; the alphabet size is not part of the ABI: use the largest letter seen
-  std::vector<uint8_t> arena((size_t)X + Y + 16, 0);
+  const size_t moff = ((size_t)X + 3) / 4 * 4;     // frames start on 4-byte boundaries
+  std::vector<uint8_t> arena(moff + (size_t)Y + 16, 0);
   int maxlet = 0;
   for (int i = 0; i < X; i++) { const int c = fr->origin[fr->origin_range.i + i]; if (c < 0 || c > 255) { fprintf(stderr, "pwlib: letter %d out of range 0..255\n", c); return none; } arena[i] = (uint8_t)c; maxlet = std::max(maxlet, c); }
-  for (int i = 0; i < Y; i++) { const int c = fr->mutant[fr->mutant_range.i + i]; if (c < 0 || c > 255) { fprintf(stderr, "pwlib: letter %d out of range 0..255\n", c); return none; } arena[(size_t)X + i] = (uint8_t)c; maxlet = std::max(maxlet, c); }
+  for (int i = 0; i < Y; i++) { const int c = fr->mutant[fr->mutant_range.i + i]; if (c < 0 || c > 255) { fprintf(stderr, "pwlib: letter %d out of range 0..255\n", c); return none; } arena[moff + i] = (uint8_t)c; maxlet = std::max(maxlet, c); }
   const int L = maxlet + 1;
   std::vector<double> subst((size_t)L * L);
   for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) subst[(size_t)i * L + j] = prob->scores->subst_scores[i][j];
@@ -518,7 +520,7 @@ intpair dptable_solve(dptable* T) {
   sc.alphabet_len = L; sc.subst = subst.data();
   sc.go = prob->scores->gap_open_score; sc.ge = prob->scores->gap_extend_score;
   pw_pair pr;
-  pr.origin_off = 0; pr.mutant_off = (uint64_t)X; pr.origin_len = X; pr.mutant_len = Y;
+  pr.origin_off = 0; pr.mutant_off = (uint64_t)moff; pr.origin_len = X; pr.mutant_len = Y;
   pr.dmin = prob->mode == BANDED_MODE ? prob->banded_params->dmin : 0;
   pr.dmax = prob->mode == BANDED_MODE ? prob->banded_params->dmax : 0;
   const bool want_table = prob->mode == STD_MODE && !env_int("PWLIB_NO_TABLE", 0);

@@ -34,8 +34,8 @@ typedef struct {
 
 /* One problem. */
 typedef struct {
-  uint64_t origin_off;  /* byte offset of the origin frame in the arena */
-  uint64_t mutant_off;  /* byte offset of the mutant frame in the arena */
+  uint64_t origin_off;  /* byte offset of the origin frame in the arena; must be a multiple of 4 */
+  uint64_t mutant_off;  /* byte offset of the mutant frame in the arena; must be a multiple of 4 */
   int32_t origin_len;   /* X */
   int32_t mutant_len;   /* Y */
   int32_t dmin, dmax;   /* banded mode: diag_range as given (it is clamped like _pw_internals.c:29-36) */

@@ -122,7 +122,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   pd.nblocks = pl.nblocks; pd.steady_b0 = pl.steady_b0; pd.steady_b1 = pl.steady_b1;
   pd.h_pitch = (X < Y ? X : Y) + 1;
   pd.tx_cap = X + Y + 1; pd.bk = bk; pd.solvable = 1;
-  std::vector<uint32_t> masks((size_t)pl.nblocks * 64 * bk + 64, 0xdeadbeefu);
+  std::vector<uint32_t> masks((size_t)pl.nblocks * 64 * bk + 64, 0xdeadbeefu);   // + slack like the product
   std::vector<T> hd;
   if (hdump) hd.assign((size_t)pl.ndiag * pd.h_pitch, T(0));
   std::vector<T> sub((size_t)L * L);
@@ -157,7 +157,8 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   tp.pairs = &pd; tp.arena = arena.data(); tp.masks = masks.data(); tp.results = &res;
   tp.transcripts = tx.data(); tp.npairs = 1;
   tp.gosign = go < 0 ? -1 : (go > 0 ? 1 : 0); tp.banded = a.banded; tp.ends = nullptr;
-  pw::trace_pair(tp, 0);
+  pw::trace_walk(tp, 0);
+  pw::trace_fixup_serial(tp, 0);
   info[4] = res.opt_i; info[5] = res.opt_j; info[6] = res.origin_idx; info[7] = res.mutant_idx;
   info[8] = res.tx_len; info[9] = res.status;
   *score = res.score;
