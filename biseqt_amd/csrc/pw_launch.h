@@ -12,7 +12,8 @@ namespace pw {
 enum { VAR_FAST_ANY_TRACK = 0,  // begin anywhere + per-diagonal best: LOCAL, B_LOCAL (END_ANCHORED rides along)
        VAR_FAST_TRACK = 1,      // begin at origin/edges + per-diagonal best: START_ANCHORED
        VAR_FAST = 2,            // begin at origin/edges, end on the table edge: GLOBAL, *OVERLAP, B_GLOBAL, B_OVERLAP
-       VAR_GENERIC = 3 };       // substitution matrix / go > 0 / score-plane dump: everything at run time
+       VAR_GENERIC = 3,         // substitution matrix / go > 0 / score-plane dump: everything at run time
+       VAR_FAST16 = 4 };        // VAR_FAST_ANY_TRACK with the steady phase in packed 16-bit (int32 kernels, BK >= 4)
 
 static const int kSupportedBK[] = {2, 4, 8, 16, 32};
 static const int kNumSupportedBK = 5;

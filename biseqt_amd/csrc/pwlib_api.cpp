@@ -164,7 +164,20 @@ int batch_build(pw_batch* b) {
   const bool bany = b->brule == pw::BRULE_ANY;
   const bool track = b->endrule == pw::END_STD_LOCAL || b->endrule == pw::END_BANDED_LOCAL;
   if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || !b->simple || b->go > 0) b->variant = pw::VAR_GENERIC;
-  else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
+  else if (bany) {
+    b->variant = pw::VAR_FAST_ANY_TRACK;
+    // packed 16-bit steady phase (pw_wave.h, WaveFill16): every running value must fit comfortably
+    int64_t maxmin = 0, maxspan16 = 0; int minbk = 1 << 30;
+    for (int32_t k = 0; k < b->n; k++) if (b->descs[k].solvable) {
+      maxmin = std::max<int64_t>(maxmin, std::min(b->pairs[k].origin_len, b->pairs[k].mutant_len));
+      maxspan16 = std::max<int64_t>(maxspan16, (int64_t)b->pairs[k].origin_len + b->pairs[k].mutant_len + 2);
+      minbk = std::min(minbk, (int)b->descs[k].bk);
+    }
+    const double mtc = std::max(mt, 0.0);
+    if (!b->use_f64 && !(b->flags & PW_FLAG_NO_PACKED16) && maxabs <= 100 && maxmin * mtc <= 20000 &&
+        maxspan16 < 60000 && minbk >= 4)
+      b->variant = pw::VAR_FAST16;
+  }
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
   for (auto& c : b->classes)

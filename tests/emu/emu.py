@@ -31,7 +31,7 @@ def lib():
 
 def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., mismatch=0., go=0., ge=0.,
           diag_range=None, origin_range=None, mutant_range=None, use_double=False, force_generic=False,
-          bk=8, want_table=False, **_):
+          bk=8, want_table=False, packed16=False, **_):
     o = np.asarray(origin, dtype=np.int32)
     m = np.asarray(mutant, dtype=np.int32)
     if L is None:
@@ -63,7 +63,7 @@ def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., misma
                          mf.ctypes.data_as(C.POINTER(C.c_int)), Y, L,
                          S.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(go), C.c_double(ge),
                          int(dr[0]), int(dr[1]), int(use_double), int(force_generic), bk,
-                         info, C.byref(score), txbuf, txcap, hp)
+                         info, C.byref(score), txbuf, txcap, hp, int(packed16))
     if rc != 0:
         raise ValueError('emu_solve rc=%d' % rc)
     out = dict(init_rc=info[0], opt=None, score=None, transcript=None, origin_idx=None,

@@ -89,9 +89,29 @@ void run_fill(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst
   });
 }
 
+template <typename T, int BK> struct Run16 {
+  static bool go(const pw::FillParams<T>&, const pw::PairDesc&) { return false; }
+};
+template <int BK> struct Run16<int32_t, BK> {
+  static bool go(const pw::FillParams<int32_t>& a, const pw::PairDesc& pd) {
+    if constexpr (BK % 4 == 0) {
+      Emu emu;
+      emu.run([&]() {
+        pw::WaveFill16<EmuP, BK> w(a, pd);
+        w.w.pair_slot = 0;
+        w.run();
+      });
+      return true;
+    } else {
+      return false;
+    }
+  }
+};
+
 template <typename T, int BK>
 void dispatch_variant(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst, int generic,
-                      int bany, int track) {
+                      int bany, int track, int packed16) {
+  if (packed16 && !generic && bany && Run16<T, BK>::go(a, pd)) return;
   if (generic) run_fill<T, BK, false, true, true>(a, pd, subst);
   else if (bany && track) run_fill<T, BK, true, true, false>(a, pd, subst);
   else if (!bany && track) run_fill<T, BK, false, true, false>(a, pd, subst);
@@ -101,7 +121,7 @@ void dispatch_variant(const pw::FillParams<T>& a, const pw::PairDesc& pd, const 
 
 template <typename T>
 int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int Y, int L,
-            const double* subst, double go, double ge, int dmin_in, int dmax_in, int force_generic, int bk,
+            const double* subst, double go, double ge, int dmin_in, int dmax_in, int force_generic, int bk, int packed16,
             int* info, double* score, char* txbuf, int txcap, double* hdump) {
   pw::Plan pl = pw::plan_problem(mode, type, X, Y, dmin_in, dmax_in);
   info[0] = pl.rc; info[1] = pl.dmin; info[2] = pl.dmax; info[3] = pl.num_rows;
@@ -143,11 +163,11 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
   switch (bk) {
-    case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track); break;
-    case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track); break;
-    case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track); break;
-    case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track); break;
-    case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track); break;
+    case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, packed16); break;
+    case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track, packed16); break;
+    case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track, packed16); break;
+    case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track, packed16); break;
+    case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track, packed16); break;
     default: return -4;
   }
   // traceback by "one lane"
@@ -175,10 +195,10 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
 extern "C" int emu_solve(int mode, int type, const int* origin, int X, const int* mutant, int Y, int L,
                          const double* subst, double go, double ge, int dmin, int dmax, int use_double,
                          int force_generic, int bk, int* info, double* score, char* txbuf, int txcap,
-                         double* hdump) {
+                         double* hdump, int packed16) {
   if (use_double)
-    return solve_T<double>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk,
+    return solve_T<double>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk, 0,
                            info, score, txbuf, txcap, hdump);
-  return solve_T<int32_t>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk,
+  return solve_T<int32_t>(mode, type, origin, X, mutant, Y, L, subst, go, ge, dmin, dmax, force_generic, bk, packed16,
                           info, score, txbuf, txcap, hdump);
 }
