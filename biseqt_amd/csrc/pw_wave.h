@@ -435,10 +435,10 @@ struct WaveFill {
 // the up / left neighbours of a register pair are again whole registers of the other parity; only the
 // two block edges need one DPP wave shift + one v_alignbit per step.
 //
-// Only the steady phase runs packed.  Ramp blocks (first / last cells of diagonals, begin rule, table
-// edges) run the predicated 32-bit code of WaveFill; state is converted at the two phase boundaries.
-// Eligibility (host planner): begin-anywhere types (LOCAL, B_LOCAL), match/mismatch scoring, go <= 0,
-// every score within +-100, min(X,Y) * match <= 20000, X + Y + 2 < 60000.
+// Blocks in which diagonals start or end run a slightly longer packed body (cellpair<EDGE = true>) that
+// needs no predication at all -- see there.  Eligibility (host planner): LOCAL and B_LOCAL (begin anywhere,
+// end anywhere: the end-cell search uses the tracked bests only), match/mismatch scoring, go <= 0, every
+// score within +-100, min(X,Y) * match <= 16000, X + Y + 2 < 32000 (steps as signed 16-bit).
 // =================================================================================================
 namespace pk {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -456,6 +456,8 @@ PW_FN uint32_t max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t,
 PW_FN uint32_t minu(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) * as_u2(b) + as_u2(c))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
+// sign mask per half (0xffff where negative); asm for the same reason as minu (else: compare + select)
+PW_FN uint32_t sign(uint32_t a) { uint32_t d; asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(d) : "v"(a)); return d; }
 #else
 PW_FN uint32_t mk(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
 PW_FN int32_t sl(uint32_t v) { return (int16_t)(v & 0xffffu); }
@@ -471,6 +473,7 @@ PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) {
   return mk((uint32_t)(sl(a) * sl(b) + sl(c)), (uint32_t)(sh(a) * sh(b) + sh(c)));
 }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
+PW_FN uint32_t sign(uint32_t a) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
 #endif
 PW_FN uint32_t both(int32_t v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 PW_FN uint32_t pack(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
@@ -484,60 +487,43 @@ struct WaveFill16 {
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
   static constexpr int32_t NEG16 = -8192;
+  static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
   using Base = WaveFill<P, int32_t, BK, true, true, false>;
-  Base w;
+  Base w;                               // geometry, feeders, mask stores and the end-cell search are shared
 
   // packed state: index p <-> even slots (2p, 2p + R) [E*] / odd slots (2p + 1, 2p + 1 + R) [O*]
   uint32_t HE[RH], UE[RH], LE[RH], HO[RH], UO[RH], LO[RH];
   uint32_t bestE[RH], bestO[RH], btE[RH], btO[RH];     // running best and the step it was first reached
   uint32_t gebE[RH], gebO[RH];                          // ge (+ the band-top block) per half
+  uint32_t tfE[RH], tfO[RH], tlE[RH], tlO[RH];          // first / last step of each diagonal
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
-  uint32_t ONE, NDELTA, MATCHV, GOV, NEGV;
+  uint32_t ONE, NDELTA, MATCHV, GOV, NEGV, LIMV;
 
   PW_FN WaveFill16(const FillParams<int32_t>& a, const PairDesc& pd) : w(a, pd, nullptr) {}
-
-  PW_FN static int32_t clamp16(int32_t v) { return v < NEG16 ? NEG16 : v; }
-
-  PW_FN void pack_state() {
-#pragma unroll
-    for (int p = 0; p < RH; p++) {
-      const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      HE[p] = pk::pack(clamp16(w.H[e0]), clamp16(w.H[e1])); HO[p] = pk::pack(clamp16(w.H[o0]), clamp16(w.H[o1]));
-      UE[p] = pk::pack(clamp16(w.U[e0]), clamp16(w.U[e1])); UO[p] = pk::pack(clamp16(w.U[o0]), clamp16(w.U[o1]));
-      LE[p] = pk::pack(clamp16(w.L[e0]), clamp16(w.L[e1])); LO[p] = pk::pack(clamp16(w.L[o0]), clamp16(w.L[o1]));
-      bestE[p] = pk::pack(clamp16(w.best[e0]), clamp16(w.best[e1]));
-      bestO[p] = pk::pack(clamp16(w.best[o0]), clamp16(w.best[o1]));
-      btE[p] = pk::pack(w.bestT[e0], w.bestT[e1]); btO[p] = pk::pack(w.bestT[o0], w.bestT[o1]);
-      OW[p] = pk::pack((int32_t)w.ow[p], (int32_t)w.ow[p + RH]);
-      MW[p] = pk::pack((int32_t)w.mw[p], (int32_t)w.mw[p + RH]);
-    }
-  }
-  PW_FN void unpack_state() {
-#pragma unroll
-    for (int p = 0; p < RH; p++) {
-      const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      w.H[e0] = pk::lo_s(HE[p]); w.H[e1] = pk::hi_s(HE[p]); w.H[o0] = pk::lo_s(HO[p]); w.H[o1] = pk::hi_s(HO[p]);
-      w.U[e0] = pk::lo_s(UE[p]); w.U[e1] = pk::hi_s(UE[p]); w.U[o0] = pk::lo_s(UO[p]); w.U[o1] = pk::hi_s(UO[p]);
-      w.L[e0] = pk::lo_s(LE[p]); w.L[e1] = pk::hi_s(LE[p]); w.L[o0] = pk::lo_s(LO[p]); w.L[o1] = pk::hi_s(LO[p]);
-      w.best[e0] = pk::lo_s(bestE[p]); w.best[e1] = pk::hi_s(bestE[p]);
-      w.best[o0] = pk::lo_s(bestO[p]); w.best[o1] = pk::hi_s(bestO[p]);
-      w.bestT[e0] = (int32_t)(btE[p] & 0xffffu); w.bestT[e1] = (int32_t)(btE[p] >> 16);
-      w.bestT[o0] = (int32_t)(btO[p] & 0xffffu); w.bestT[o1] = (int32_t)(btO[p] >> 16);
-      w.ow[p] = OW[p] & 0xffffu; w.ow[p + RH] = OW[p] >> 16;
-      w.mw[p] = MW[p] & 0xffffu; w.mw[p + RH] = MW[p] >> 16;
-    }
-  }
 
   // Two cells at once.  `acc` collects the INVERTED tie bits (1 = candidate not kept), 4 bits per cell:
   // bit 0 B, bit 1 D, bit 2 I; bit 3 (M) stays 0 -- with go <= 0 the walker never needs it: the first
   // kept op is M exactly when none of B, D, I is kept (pw_first_op).
+  //
+  // EDGE = false: steady phase, every in-band diagonal holds an in-table cell.
+  // EDGE = true : blocks in which diagonals start or end.  No state is frozen; instead
+  //   * a diagonal that has not started yet (cells with a negative coordinate) may not begin an alignment:
+  //     its B candidate is the sentinel instead of 0.  Such cells have only sentinels as predecessors and
+  //     letters outside the sequences match nothing, so they stay at the sentinel and in-table cells
+  //     never pick them;
+  //   * a diagonal that has ended keeps computing cells beyond the table; nothing in the table reads them
+  //     (predecessors have smaller coordinates), their tie nibbles land in mask slots the walker never
+  //     visits, and they are kept out of the running best by lowering them by 32767 first.
+  template <bool EDGE>
   PW_FN void cellpair(uint32_t& Hs, uint32_t& Us, uint32_t& Ls, uint32_t& bests, uint32_t& bts, uint32_t geb,
-                      uint32_t& acc, uint32_t up, uint32_t left, uint32_t oc, uint32_t mc, uint32_t tv) {
+                      uint32_t tf, uint32_t tl, uint32_t& acc, uint32_t up, uint32_t left, uint32_t oc,
+                      uint32_t mc, uint32_t tv) {
     const uint32_t ne = pk::minu(oc ^ mc, ONE);                 // 0 where the letters match
     const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
     uint32_t Hn = pk::max(pk::max(up, left), hM);
-    Hn = pk::max(Hn, 0u);                                        // B: an alignment may begin anywhere, score 0
+    if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf)) & NEGV);   // B = 0 once started, sentinel before
+    else Hn = pk::max(Hn, 0u);                                   // B: an alignment may begin anywhere, score 0
     const uint32_t nD = pk::minu(pk::sub(Hn, up), ONE);
     const uint32_t nI = pk::minu(pk::sub(Hn, left), ONE);
     const uint32_t nB = pk::minu(Hn, ONE);
@@ -546,13 +532,15 @@ struct WaveFill16 {
     Ls = pk::mad(nI, GOV, hg);
     // halves hold values <= 7: plain 32-bit shift-adds never carry across the halves
     acc = (acc << 4) + (((nI << 2) + (nD << 1)) + nB);
-    const uint32_t bn = pk::max(bests, Hn);
+    const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv)) & LIMV) : Hn;
+    const uint32_t bn = pk::max(bests, Ht);
     const uint32_t u = pk::minu(pk::sub(bn, bests), ONE);       // 1 where the best strictly improved
     bts = pk::mad(u, pk::sub(tv, bts), bts);
     bests = bn;
     Hs = Hn;
   }
 
+  template <bool EDGE>
   PW_FN void iteration16(int it, int k) {
     const uint32_t tv0 = pk::both(2 * it), tv1 = pk::both(2 * it + 1);
     // even step: slot 0 <- previous lane's last slot, slot R <- own slot R - 1
@@ -561,12 +549,13 @@ struct WaveFill16 {
       const uint32_t up0 = pk::align16(UO[RH - 1], prev);         // (prev.hi, own.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
-        cellpair(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], k < 4 ? accE[p] : acc2E[p],
-                 p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0);
+        cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], k < 4 ? accE[p] : acc2E[p],
+                       p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0);
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | feeder)
     {
-      const uint32_t feed = Base::feed_byte(w.fo_lo, w.fo_hi, k);
+      const int oi = w.xfeed_o + it;
+      const uint32_t feed = (uint32_t)oi < (uint32_t)w.X ? Base::feed_byte(w.fo_lo, w.fo_hi, k) : SENT_O;
       const uint32_t nxt = xshl1<P>(OW[0], feed);
       const uint32_t last = pk::align16(nxt, OW[0]);
 #pragma unroll
@@ -579,12 +568,13 @@ struct WaveFill16 {
       const uint32_t leftl = pk::align16(nxt, LE[0]);              // (own.hi, next.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
-        cellpair(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], k < 4 ? accO[p] : acc2O[p],
-                 UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1);
+        cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], k < 4 ? accO[p] : acc2O[p],
+                       UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1);
     }
     // mutant window moves on: first register <- (previous lane's last.hi | feeder, own last.lo)
     {
-      const uint32_t feed = Base::feed_byte(w.fm_lo, w.fm_hi, k) << 16;
+      const int mi = w.yfeed_m + it;
+      const uint32_t feed = ((uint32_t)mi < (uint32_t)w.Y ? Base::feed_byte(w.fm_lo, w.fm_hi, k) : SENT_M) << 16;
       const uint32_t prv = xshr1<P>(MW[RH - 1], feed);
       const uint32_t first = pk::align16(MW[RH - 1], prv);
 #pragma unroll
@@ -593,11 +583,12 @@ struct WaveFill16 {
     }
   }
 
+  template <bool EDGE>
   PW_FN void block16(int b) {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
 #pragma unroll
-    for (int k = 0; k < 8; k++) iteration16(8 * b + k, k);
+    for (int k = 0; k < 8; k++) iteration16<EDGE>(8 * b + k, k);
     // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept)
 #pragma unroll
     for (int p = 0; p < RH; p++) {
@@ -606,35 +597,55 @@ struct WaveFill16 {
       w.m[2 * p + 1] = 0x77777777u - (((accO[p] & 0xffffu) << 16) | (acc2O[p] & 0xffffu));
       w.m[2 * p + 1 + R] = 0x77777777u - ((accO[p] & 0xffff0000u) | (acc2O[p] >> 16));
     }
-    w.xbase += 8; w.ybase += 8;
   }
+
+  PW_FN int tfirst_of(int j) const {      // first step of slot j's diagonal; never for a diagonal outside the band
+    const int dd = w.lane * BK + j, d = w.pd.dmin + dd;
+    return dd < w.ndiag ? (d < 0 ? -d : d) - w.pd.s0 : 32767;
+  }
+  PW_FN int tlast_of(int j) const {
+    const int dd = w.lane * BK + j, d = w.pd.dmin + dd;
+    if (dd >= w.ndiag) return -1;
+    const int len = 1 + (d > 0 ? 0 : d) + (w.X - d > w.Y ? w.Y : w.X - d);
+    return (d < 0 ? -d : d) - w.pd.s0 + 2 * (len - 1);
+  }
+  PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)w.X ? (uint32_t)w.oseq[i] : SENT_O; }
+  PW_FN uint32_t letter_m(int i) const { return (uint32_t)i < (uint32_t)w.Y ? (uint32_t)w.mseq[i] : SENT_M; }
 
   PW_FN void run() {
     w.init();
     const FillParams<int32_t>& a = w.a;
-    ONE = 0x00010001u; NEGV = pk::both(NEG16);
+    ONE = 0x00010001u; NEGV = pk::both(NEG16); LIMV = pk::both(-32767);
     NDELTA = pk::both(a.mismatch - a.match); MATCHV = pk::both(a.match); GOV = pk::both(a.go);
 #pragma unroll
     for (int p = 0; p < RH; p++) {
       const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
       gebE[p] = pk::pack(a.ge + (w.blkL[e0] ? NEG16 : 0), a.ge + (w.blkL[e1] ? NEG16 : 0));
       gebO[p] = pk::pack(a.ge + (w.blkL[o0] ? NEG16 : 0), a.ge + (w.blkL[o1] ? NEG16 : 0));
+      tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
+      tlE[p] = pk::pack(tlast_of(e0), tlast_of(e1)); tlO[p] = pk::pack(tlast_of(o0), tlast_of(o1));
+      HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
+      bestE[p] = bestO[p] = NEGV; btE[p] = btO[p] = 0;
+      OW[p] = pk::pack((int32_t)letter_o(w.xbase + p - 1), (int32_t)letter_o(w.xbase + p + RH - 1));
+      MW[p] = pk::pack((int32_t)letter_m(w.ybase - p - 1), (int32_t)letter_m(w.ybase - p - RH - 1));
     }
-    bool packed = false;
     w.feed_issue(0);
     for (int b = 0; b < w.pd.nblocks; b++) {
       w.feed_commit(b);
       if (b + 1 < w.pd.nblocks) w.feed_issue(b + 1);
-      if (b >= w.pd.steady_b0 && b < w.pd.steady_b1) {
-        if (!packed) { pack_state(); packed = true; }
-        block16(b);
-      } else {
-        if (packed) { unpack_state(); packed = false; }
-        w.template block<true>(b);
-      }
+      if (b >= w.pd.steady_b0 && b < w.pd.steady_b1) block16<false>(b);
+      else block16<true>(b);
       w.store_masks(b);
     }
-    if (packed) unpack_state();
+    // hand the per-diagonal bests to the shared end-cell search
+#pragma unroll
+    for (int p = 0; p < RH; p++) {
+      const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
+      w.best[e0] = pk::lo_s(bestE[p]); w.best[e1] = pk::hi_s(bestE[p]);
+      w.best[o0] = pk::lo_s(bestO[p]); w.best[o1] = pk::hi_s(bestO[p]);
+      w.bestT[e0] = (int32_t)(btE[p] & 0xffffu); w.bestT[e1] = (int32_t)(btE[p] >> 16);
+      w.bestT[o0] = (int32_t)(btO[p] & 0xffffu); w.bestT[o1] = (int32_t)(btO[p] >> 16);
+    }
     w.finish();
   }
 };

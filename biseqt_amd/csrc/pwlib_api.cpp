@@ -174,8 +174,8 @@ int batch_build(pw_batch* b) {
       minbk = std::min(minbk, (int)b->descs[k].bk);
     }
     const double mtc = std::max(mt, 0.0);
-    if (!b->use_f64 && !(b->flags & PW_FLAG_NO_PACKED16) && maxabs <= 100 && maxmin * mtc <= 20000 &&
-        maxspan16 < 60000 && minbk >= 4)
+    if (!b->use_f64 && track && !(b->flags & PW_FLAG_NO_PACKED16) && maxabs <= 100 && maxmin * mtc <= 16000 &&
+        maxspan16 < 32000 && minbk >= 4)
       b->variant = pw::VAR_FAST16;
   }
   else if (track) b->variant = pw::VAR_FAST_TRACK;
