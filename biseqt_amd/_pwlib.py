@@ -113,7 +113,7 @@ SIZEOF = dict(intpair=8, alnscores=24, alnframe=32, std_alnparams=4, banded_alnp
 EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_last_error', 'pw_device_count', 'pw_batch_create', 'pw_batch_destroy',
            'pw_batch_init_rc', 'pw_batch_band', 'pw_batch_pair_cells', 'pw_batch_cells',
-           'pw_batch_algorithmic_bytes', 'pw_batch_score_type', 'pw_batch_upload_arena',
+           'pw_batch_algorithmic_bytes', 'pw_batch_score_type', 'pw_batch_kernel_name', 'pw_batch_upload_arena',
            'pw_batch_arena_device', 'pw_batch_solve', 'pw_batch_traceback',
            'pw_batch_traceback_from', 'pw_batch_sync', 'pw_batch_results_device',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
@@ -162,6 +162,8 @@ def load():
     lib.pw_batch_algorithmic_bytes.argtypes = [C.c_void_p]
     lib.pw_batch_algorithmic_bytes.restype = C.c_int64
     lib.pw_batch_score_type.argtypes = [C.c_void_p]
+    lib.pw_batch_kernel_name.argtypes = [C.c_void_p]
+    lib.pw_batch_kernel_name.restype = C.c_char_p
     lib.pw_batch_upload_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.pw_batch_arena_device.argtypes = [C.c_void_p]
     lib.pw_batch_arena_device.restype = C.c_void_p

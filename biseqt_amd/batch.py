@@ -151,6 +151,10 @@ class BatchAligner(object):
     def score_dtype(self):
         return 'f64' if self.lib.pw_batch_score_type(self.handle) else 'i32'
 
+    @property
+    def kernel_name(self):
+        return self.lib.pw_batch_kernel_name(self.handle).decode()
+
     def init_rc(self, k):
         return self.lib.pw_batch_init_rc(self.handle, k)
 

@@ -2,11 +2,16 @@
 // and the run-time dispatch over the per-(type, BK) fill translation units.
 #include "pw_device.h"
 
+#include <stdlib.h>
+
 namespace pw {
 
-__global__ __launch_bounds__(64) void k_trace(const TraceParams p) {
-  const int pair = (int)(blockIdx.x * 64u + threadIdx.x);
-  if (pair < p.npairs) trace_walk(p, pair);
+// `walkers` lanes of each wavefront walk one pair each (tuning knob PWLIB_WALKERS_PER_WAVE; measured on
+// MI355X: 1..64 all land within 1.0-1.4 ms for 10 000 2 kb pairs -- the walk is bound by instructions per
+// step, not by latency -- so the default packs 64).
+__global__ __launch_bounds__(64) void k_trace(const TraceParams p, const int walkers) {
+  const int pair = (int)blockIdx.x * walkers + (int)threadIdx.x;
+  if ((int)threadIdx.x < walkers && pair < p.npairs) trace_walk(p, pair);
 }
 
 // K4b, wave-parallel: one wavefront per pair, 64 transcript positions per pass.  The (x, y) each
@@ -39,7 +44,13 @@ __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
 
 hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
   if (p.npairs <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_trace, dim3((unsigned)((p.npairs + 63) / 64)), dim3(64), 0, st, p);
+  static int walkers = 0;
+  if (walkers == 0) {
+    const char* e = getenv("PWLIB_WALKERS_PER_WAVE");      // tuning knob; default measured on MI355X
+    walkers = e ? atoi(e) : 64;
+    if (walkers < 1 || walkers > 64) walkers = 64;
+  }
+  hipLaunchKernelGGL(k_trace, dim3((unsigned)((p.npairs + walkers - 1) / walkers)), dim3(64), 0, st, p, walkers);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_trace_fixup, dim3((unsigned)p.npairs), dim3(64), 0, st, p);

@@ -119,8 +119,6 @@ struct WaveFill {
     return oc == mc ? a.match : a.mismatch;
   }
 
-  PW_FN static uint32_t umin1(uint32_t v) { return v < 1u ? v : 1u; }
-
   // One cell of slot J on step t (lane-local coordinates x, y).
   template <bool RAMP, int J>
   PW_FN void cell(T up, T left, uint32_t oc, uint32_t mc, int x, int y, int t) {
@@ -151,26 +149,6 @@ struct WaveFill {
       Hn = hI > Hn ? hI : Hn;
       Hn = hM > Hn ? hM : Hn;
     }
-#if defined(PW_ARITH_SELECT)
-    if (Tr::is_int && !GENERIC && !RAMP && BANY) {
-      // tie bits as 0/1 integers computed in the vector ALU only (no compare -> SGPR -> select round trip
-      // on the recurrence's critical path): n* = min(Hn - cand, 1) is 0 iff the candidate is kept
-      const uint32_t nD = umin1((uint32_t)(Hn - hD)), nI = umin1((uint32_t)(Hn - hI));
-      const uint32_t nM = umin1((uint32_t)(Hn - hM)), nB = umin1((uint32_t)Hn);
-      const T Hgb = Hn + a.ge + blkL[J];
-      U[J] = Hgb + (T)nD * a.go;
-      L[J] = Hgb + (T)nI * a.go;
-      const uint32_t inv = nB | (nD << 1) | (nI << 2) | (nM << 3);
-      m[J] = (m[J] << 4) | (inv ^ 15u);
-      H[J] = Hn;
-      if (TRACK) {
-        const bool upd = Hn > best[J];
-        best[J] = upd ? Hn : best[J];
-        bestT[J] = upd ? t : bestT[J];
-      }
-      return;
-    }
-#endif
     const bool bB = ball && (Hn == T(0));
     const bool bD = (hD == Hn), bI = (hI == Hn), bM = (hM == Hn);
     // what this cell offers downwards (as a D predecessor) and rightwards (as an I predecessor):
@@ -728,6 +706,18 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
       nms += (op == 3);
       x -= (op != 2); y -= (op != 1);
       prev = op;
+      if (op == 3) {
+        // fast path: a run of diagonal moves stays on this diagonal and, while the cell index n inside the
+        // block stays >= 0, inside this very dword.  After M the next op is the cell's first kept choice,
+        // which is M again exactly when none of B, D, I is kept: (nibble & 7) == 0.
+        int n = ((t & 15) >> 1) - 1;                 // cell index of the new (x, y) within the dword
+        while (n >= 0 && pos > 0 && x > 0 && y > 0) {
+          const uint32_t nb = (w >> (4 * (7 - n))) & 7u;
+          if (nb != 0) break;
+          tx[--pos] = 'X';
+          nms++; x--; y--; n--;
+        }
+      }
     }
   }
   r.origin_idx = x; r.mutant_idx = y;

@@ -285,6 +285,21 @@ int64_t pw_batch_cells(const pw_batch* b) { return b->cells; }
 int64_t pw_batch_algorithmic_bytes(const pw_batch* b) { return b->alg_bytes; }
 int pw_batch_score_type(const pw_batch* b) { return b->use_f64 ? 1 : 0; }
 
+const char* pw_batch_kernel_name(const pw_batch* b) {
+  static thread_local char name[96];
+  int bk = 0; size_t most = 0;
+  for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; }
+  const char* t = b->use_f64 ? "double" : "int";
+  switch (b->variant) {
+    case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d>", bk); break;
+    case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;
+    case pw::VAR_FAST_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, false, true, false>", t, bk); break;
+    case pw::VAR_FAST: snprintf(name, sizeof name, "k_fill<%s, %d, false, false, false>", t, bk); break;
+    default: snprintf(name, sizeof name, "k_fill<%s, %d, false, true, true>", t, bk); break;
+  }
+  return name;
+}
+
 int pw_batch_upload_arena(pw_batch* b, const uint8_t* host, uint64_t bytes) {
   if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
   HIP_TRY(hipSetDevice(b->device));

@@ -80,6 +80,7 @@ int64_t pw_batch_pair_cells(const pw_batch* b, int32_t k);                   /* 
 int64_t pw_batch_cells(const pw_batch* b);                                   /* sum over solvable pairs */
 int64_t pw_batch_algorithmic_bytes(const pw_batch* b);                       /* 0.5 B/cell + X+Y + 32 per pair */
 int pw_batch_score_type(const pw_batch* b);                                  /* 0 int32, 1 double */
+const char* pw_batch_kernel_name(const pw_batch* b);                         /* fill kernel of the largest pair class */
 
 int pw_batch_upload_arena(pw_batch* b, const uint8_t* host_arena, uint64_t bytes);   /* synchronous H2D */
 void* pw_batch_arena_device(pw_batch* b);

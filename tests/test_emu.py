@@ -84,3 +84,36 @@ def test_emu_steady_phase_and_score_plane(oracle):
     for x in range(41):
         for y in range(34):
             assert plane[x - y + 33, min(x, y)] == H[x, y], (x, y)
+
+
+def test_emu_packed16_local(oracle):
+    """The packed 16-bit kernel body (WaveFill16: LOCAL / B_LOCAL only) against the oracle: steady and
+    edge blocks, clamped bands, sub-word sequences, every supported BK."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(16)
+    n = 0
+    for trial in range(70):
+        L = int(rng.choice([2, 4]))
+        X = int(rng.integers(0, 260)) if trial % 4 else int(rng.integers(0, 12))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 9))).astype(np.uint8)
+        if rng.random() < 0.3:
+            m = np.concatenate([rng.integers(0, L, int(rng.integers(0, 30))).astype(np.uint8), m])
+        kw = dict(L=L, match=float(rng.choice([1, 2, 5])), mismatch=float(rng.choice([0, -1, -3])),
+                  go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
+        if rng.random() < 0.7:
+            r, c = int(rng.integers(1, 50)), int(rng.integers(-10, 10))
+            kw.update(mode=1, alntype=1, diag_range=(c - r, c + r))
+            nd = min(c + r, X) - max(c - r, -len(m)) + 1
+        else:
+            kw.update(mode=0, alntype=1)
+            nd = X + len(m) + 1
+        bk = next((b for b in (4, 8, 16, 32) if b >= (4, 8, 16)[trial % 3] and 64 * b >= nd), None)
+        if bk is None:
+            continue
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=bk, packed16=True, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
+        n += 1
+    assert n > 50
