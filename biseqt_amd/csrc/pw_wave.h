@@ -639,6 +639,7 @@ PW_FN int pw_first_op(uint32_t mask) {   // index of the lowest set bit: 0 B, 1 
 }
 
 struct __attribute__((aligned(8))) U4 { uint32_t x, y, z, w; };
+struct __attribute__((packed)) PackedU64 { uint64_t v; };   // an 8-byte store at any byte address
 
 // ---- K4a: the walk --------------------------------------------------------------------------------
 // One lane walks one pair; a wavefront holds 64 walkers.  The walk is a chain of dependent steps, and
@@ -707,15 +708,22 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
       x -= (op != 2); y -= (op != 1);
       prev = op;
       if (op == 3) {
-        // fast path: a run of diagonal moves stays on this diagonal and, while the cell index n inside the
+        // bulk step: a run of diagonal moves stays on this diagonal and, while the cell index n inside the
         // block stays >= 0, inside this very dword.  After M the next op is the cell's first kept choice,
-        // which is M again exactly when none of B, D, I is kept: (nibble & 7) == 0.
-        int n = ((t & 15) >> 1) - 1;                 // cell index of the new (x, y) within the dword
-        while (n >= 0 && pos > 0 && x > 0 && y > 0) {
-          const uint32_t nb = (w >> (4 * (7 - n))) & 7u;
-          if (nb != 0) break;
-          tx[--pos] = 'X';
-          nms++; x--; y--; n--;
+        // which is M again exactly when none of B, D, I is kept: (nibble & 7) == 0.  Count those cells
+        // with one ctz and write eight 'X' at once: ops are written backwards, so the bytes below the
+        // run are overwritten by the ops that follow (the slot's first 8 bytes are left to the slow path).
+        const int n = ((t & 15) >> 1) - 1;           // cell index of the new (x, y) within the dword
+        if (n >= 0 && pos >= 16) {
+          const uint64_t v = (uint64_t)((w & 0x77777777u) >> (4 * (7 - n))) | ((uint64_t)1 << (4 * (n + 1)));
+          int k = (int)(__builtin_ctzll(v) >> 2);     // pure-M cells ahead, at most n + 1
+          const int lim = x < y ? x : y;               // a diagonal move needs x >= 1 and y >= 1
+          k = k < lim ? k : lim;
+          if (k > 0) {
+            PackedU64 xs; xs.v = 0x5858585858585858ull;
+            *(PackedU64*)(tx + pos - 8) = xs;
+            pos -= k; nms += k; x -= k; y -= k;
+          }
         }
       }
     }
