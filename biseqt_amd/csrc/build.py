@@ -24,6 +24,7 @@ ARCH = 'gfx950'
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
           '-Wno-unused-function'] + os.environ.get('PW_EXTRA_CXXFLAGS', '').split()
 BKS = (2, 4, 8, 16, 32)
+PACKED_BKS = (4, 8, 12, 16, 20, 24, 28, 32)
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
 
@@ -36,6 +37,10 @@ def _jobs():
             cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
                                       os.path.join(HERE, 'pw_fill_tu.hip'), '-o', obj]
             jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tu.hip')]))
+    for bk in PACKED_BKS:
+        obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d.o' % bk)
+        cmd = [HIPCC] + COMMON + ['-DPW_BK=%d' % bk, '-c', os.path.join(HERE, 'pw_fill16_tu.hip'), '-o', obj]
+        jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill16_tu.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_trace.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_trace.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_trace.hip')]))

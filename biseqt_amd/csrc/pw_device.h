@@ -55,29 +55,13 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
   w.run();
 }
 
+// Lane-packed 16-bit kernel: one wavefront = WaveDesc.count pairs side by side (pw_wave.h, WaveFill16).
 template <int BK>
 __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int32_t> a) {
-  const int slot = (int)blockIdx.x;
-  const int pair = a.order ? a.order[slot] : slot;
-  const PairDesc pd = a.pairs[pair];
-  WaveFill16<DevP, BK> w(a, pd);
-  w.w.pair_slot = pair;
+  const WaveDesc wd = a.waves[blockIdx.x];
+  WaveFill16<DevP, BK> w(a, wd);
   w.run();
 }
-
-template <typename T, int BK> struct Launch16 {
-  static hipError_t go(const FillParams<T>&, int, hipStream_t) { return hipErrorInvalidValue; }
-};
-template <int BK> struct Launch16<int32_t, BK> {
-  static hipError_t go(const FillParams<int32_t>& a, int nblocks, hipStream_t st) {
-    if constexpr (BK % 4 == 0) {
-      hipLaunchKernelGGL((k_fill16<BK>), dim3((unsigned)nblocks), dim3(64), 0, st, a);
-      return hipGetLastError();
-    } else {
-      return hipErrorInvalidValue;
-    }
-  }
-};
 
 template <typename T, int BK>
 hipError_t launch_variant(const FillParams<T>& a, int variant, int nblocks, hipStream_t st) {
@@ -87,7 +71,6 @@ hipError_t launch_variant(const FillParams<T>& a, int variant, int nblocks, hipS
     case VAR_FAST_TRACK: hipLaunchKernelGGL((k_fill<T, BK, false, true, false>), grid, block, 0, st, a); break;
     case VAR_FAST: hipLaunchKernelGGL((k_fill<T, BK, false, false, false>), grid, block, 0, st, a); break;
     case VAR_GENERIC: hipLaunchKernelGGL((k_fill<T, BK, false, true, true>), grid, block, 0, st, a); break;
-    case VAR_FAST16: return Launch16<T, BK>::go(a, nblocks, st);
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -13,13 +13,17 @@ enum { VAR_FAST_ANY_TRACK = 0,  // begin anywhere + per-diagonal best: LOCAL, B_
        VAR_FAST_TRACK = 1,      // begin at origin/edges + per-diagonal best: START_ANCHORED
        VAR_FAST = 2,            // begin at origin/edges, end on the table edge: GLOBAL, *OVERLAP, B_GLOBAL, B_OVERLAP
        VAR_GENERIC = 3,         // substitution matrix / go > 0 / score-plane dump: everything at run time
-       VAR_FAST16 = 4 };        // VAR_FAST_ANY_TRACK with the steady phase in packed 16-bit (int32 kernels, BK >= 4)
+       VAR_FAST16 = 4 };        // LOCAL / B_LOCAL in packed 16-bit, several pairs per wavefront (launch_fill16)
 
 static const int kSupportedBK[] = {2, 4, 8, 16, 32};
 static const int kNumSupportedBK = 5;
 
 hipError_t launch_fill(const FillParams<int32_t>& a, int variant, int bk, int nblocks, hipStream_t st);
 hipError_t launch_fill(const FillParams<double>& a, int variant, int bk, int nblocks, hipStream_t st);
+// lane-packed 16-bit kernel (VAR_FAST16): one block per WaveDesc
+static const int kPackedBK[] = {4, 8, 12, 16, 20, 24, 28, 32};
+static const int kNumPackedBK = 8;
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int nwaves, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
 
 }  // namespace pw

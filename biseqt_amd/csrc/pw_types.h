@@ -52,8 +52,20 @@ struct PairDesc {
   int32_t tx_cap;      // bytes in the transcript slot (>= X + Y + 1)
   int32_t bk;          // diagonals per lane of the fill kernel that owns this pair (mask plane layout)
   int32_t solvable;    // 0: dptable_init fails for this pair (or its table is empty); kernels skip it
-  int32_t pad_[2];
+  int32_t nl;          // lanes that hold this pair = row length of its mask plane (64 unless lane-packed)
+  int32_t pad_;
 };                     // 96 bytes
+
+// One wavefront of the lane-packed fill kernel: `count` pairs side by side, `nl` lanes each.
+struct WaveDesc {
+  int32_t first;       // index into the launch order of the wave's first pair
+  int32_t count;       // pairs in this wave (<= 64 / nl)
+  int32_t nblocks;     // max over its pairs
+  int32_t steady_b0;   // blocks [steady_b0, steady_b1) are steady for ALL of its pairs
+  int32_t steady_b1;
+  int32_t nl;
+  int32_t pad_[2];
+};                     // 32 bytes
 
 // Per-pair result record (device and host; identical to the public pw_result of include/pw_batch.h).
 // 32 bytes, the unit the multi-GPU gather moves.
@@ -75,6 +87,7 @@ template <typename T>
 struct FillParams {
   const PairDesc* pairs;
   const int32_t* order;       // launch order (longest first) or null
+  const WaveDesc* waves;      // lane-packed kernels: one descriptor per wavefront
   const uint8_t* arena;
   uint32_t* masks;
   T* hdump;                   // score plane or null
@@ -102,17 +115,16 @@ struct TraceParams {
 };
 
 // ---- mask plane addressing (shared by fill, traceback and tests) -------------------------------
-// Per pair the plane is [nblocks][BK / G][64 lanes][G] dwords, G = min(4, BK): one 16-byte
-// (or 8-byte for BK = 2) store per lane and group, 1 KiB contiguous per wave store instruction.
+// Per pair the plane is [nblocks][BK / G][nl lanes][G] dwords, G = min(4, BK): one 16-byte
+// (or 8-byte for BK = 2) store per lane and group, nl * 16 B contiguous per group and store instruction.
 // A dword holds the 8 cells one diagonal slot visits in a 16-step block, first cell in the top nibble.
 static inline int mask_group(int bk) { return bk < 4 ? bk : 4; }
-static inline uint64_t mask_words_per_block(int bk) { return (uint64_t)64 * bk; }
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-static inline uint64_t mask_word_index(int bk, int b, int lane, int j) {
+static inline uint64_t mask_word_index(int bk, int nl, int b, int lane, int j) {
   const int G = bk < 4 ? bk : 4;
-  return ((uint64_t)((uint64_t)b * (bk / G) + (j / G)) * 64 + lane) * G + (j % G);
+  return ((uint64_t)((uint64_t)b * (bk / G) + (j / G)) * nl + lane) * G + (j % G);
 }
 
 }  // namespace pw

@@ -297,7 +297,7 @@ struct WaveFill {
     if (lane * BK < ndiag) {
       uint32_t* dst = a.masks + pd.mask_off;
 #pragma unroll
-      for (int j = 0; j < BK; j++) dst[mask_word_index(BK, b, lane, j)] = m[j];
+      for (int j = 0; j < BK; j++) dst[mask_word_index(BK, pd.nl, b, lane, j)] = m[j];
     }
   }
 
@@ -429,13 +429,15 @@ PW_FN u2_t as_u2(uint32_t v) { return __builtin_bit_cast(u2_t, v); }
 PW_FN uint32_t add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) + as_u2(b))); }
 PW_FN uint32_t sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) - as_u2(b))); }
 PW_FN uint32_t max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(as_s2(a), as_s2(b))); }
-// min as inline asm: the optimizer would rewrite min(x, 1) into compare + select per half (the very pattern this
-// kernel avoids); the price is an occasional s_nop the hazard recogniser puts behind an opaque asm result
-PW_FN uint32_t minu(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// NB min(x, 1) and (x >> 15) & c with LITERAL constants would be rewritten by the optimizer into compare +
+// select per half (the very pattern this kernel avoids), and inline asm gets padded with s_nop by the
+// hazard recogniser.  Callers therefore pass the constants in registers made opaque once (pk::opaque).
+PW_FN uint32_t minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_u2(a), as_u2(b))); }
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) * as_u2(b) + as_u2(c))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
-// sign mask per half (0xffff where negative); asm for the same reason as minu (else: compare + select)
-PW_FN uint32_t sign(uint32_t a) { uint32_t d; asm("v_pk_ashrrev_i16 %0, 15, %1" : "=v"(d) : "v"(a)); return d; }
+// sign mask per half (0xffff where negative): arithmetic shift by sh15 = (15, 15) held in an opaque register
+PW_FN uint32_t sign(uint32_t a, uint32_t sh15) { return __builtin_bit_cast(uint32_t, (s2_t)(as_s2(a) >> as_s2(sh15))); }
+PW_FN uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 #else
 PW_FN uint32_t mk(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
 PW_FN int32_t sl(uint32_t v) { return (int16_t)(v & 0xffffu); }
@@ -451,7 +453,8 @@ PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) {
   return mk((uint32_t)(sl(a) * sl(b) + sl(c)), (uint32_t)(sh(a) * sh(b) + sh(c)));
 }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
-PW_FN uint32_t sign(uint32_t a) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
+PW_FN uint32_t sign(uint32_t a, uint32_t) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
+PW_FN uint32_t opaque(uint32_t v) { return v; }
 #endif
 PW_FN uint32_t both(int32_t v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 PW_FN uint32_t pack(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
@@ -659,7 +662,7 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
   const int ei = p.ends ? p.ends[2 * pair] : r.opt_i;
   const int ej = p.ends ? p.ends[2 * pair + 1] : r.opt_j;
   if (ei < 0 || ej < 0) { r.tx_len = 0; r.status = 0; p.results[pair] = r; return; }
-  const int dmin = pdv.dmin, s0 = pdv.s0, ndiag = pdv.ndiag, bk = pdv.bk, gosign = p.gosign;
+  const int dmin = pdv.dmin, s0 = pdv.s0, ndiag = pdv.ndiag, bk = pdv.bk, nl = pdv.nl, gosign = p.gosign;
   int x = ei, y = ej;
   if (p.banded) {                 // _xy_from_cellpos (_pw_internals.c:100-114)
     const int d = ei + dmin;
@@ -667,7 +670,6 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
   }
   const uint32_t* __restrict__ plane = p.masks + pdv.mask_off;
   uint8_t* __restrict__ tx = p.transcripts + pdv.tx_off;
-  const int lg = bk == 2 ? 1 : bk == 4 ? 2 : bk == 8 ? 3 : bk == 16 ? 4 : 5;   // log2(bk)
   const int lgG = bk < 4 ? 1 : 2;               // log2 of the dwords per lane group (pw_types.h: mask_word_index)
   const int G = 1 << lgG;
   const int njg = bk >> lgG;
@@ -679,19 +681,20 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
     // ---- refill: groups of block cb and cb - 1 around the current cell ----
     const int dd0 = x - y - dmin, t0 = x + y - s0;
     if (x < 0 || y < 0 || dd0 < 0 || dd0 >= ndiag) { bad = 1; break; }   // never expected: see below
-    const int cln = dd0 >> lg, cjg = (dd0 & (bk - 1)) >> lgG, cb = t0 >> 4;
+    const int cln = dd0 / bk, cjg = (dd0 - cln * bk) >> lgG, cb = t0 >> 4;
     // two unconditional 16-byte loads issued back to back (for bk = 2 a group is 8 bytes and the upper half
     // of the load is the neighbouring lane's group: in bounds thanks to the slack behind the mask workspace)
     const int cbm = cb > 0 ? cb - 1 : 0;
-    const U4 c0 = *(const U4*)(plane + ((uint64_t)((uint64_t)cb * njg + cjg) * 64 + cln) * G);
-    const U4 c1 = *(const U4*)(plane + ((uint64_t)((uint64_t)cbm * njg + cjg) * 64 + cln) * G);
+    const U4 c0 = *(const U4*)(plane + ((uint64_t)((uint64_t)cb * njg + cjg) * nl + cln) * G);
+    const U4 c1 = *(const U4*)(plane + ((uint64_t)((uint64_t)cbm * njg + cjg) * nl + cln) * G);
     // ---- step while the cell is inside the cached window ----
     while (true) {
       const int dd = x - y - dmin, t = x + y - s0;
       // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
       if (x < 0 || y < 0 || dd < 0 || dd >= ndiag) { bad = 1; done = true; break; }
-      const int ln = dd >> lg, j = dd & (bk - 1), jg = j >> lgG, b = t >> 4;
-      if (ln != cln || jg != cjg || (b != cb && b != cb - 1)) break;          // miss: refill
+      // inside the cached window?  (bk need not be a power of two: compare against the window's diagonal range)
+      const int j = dd - cln * bk, jg = j >> lgG, b = t >> 4;
+      if (j < 0 || j >= bk || jg != cjg || (b != cb && b != cb - 1)) break;   // miss: refill
       const int q = j & (G - 1);
       const uint32_t wx = (b == cb) ? c0.x : c1.x, wy = (b == cb) ? c0.y : c1.y;
       const uint32_t wz = (b == cb) ? c0.z : c1.z, ww = (b == cb) ? c0.w : c1.w;

@@ -59,6 +59,8 @@ struct pw_batch {
   std::vector<pw::Plan> plans;
   std::vector<pw::PairDesc> descs;
   std::vector<BkClass> classes;
+  std::vector<pw::WaveDesc> waves;      // lane-packed kernel: one per wavefront
+  pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
   // device
   uint8_t* d_arena = nullptr; uint64_t arena_bytes = 0;
@@ -87,6 +89,7 @@ int batch_free_device(pw_batch* b) {
   if (b->d_tx) (void)hipFree(b->d_tx);
   if (b->d_subst) (void)hipFree(b->d_subst);
   if (b->d_ends) (void)hipFree(b->d_ends);
+  if (b->d_waves) (void)hipFree(b->d_waves);
   if (b->ev_fill0) (void)hipEventDestroy(b->ev_fill0);
   if (b->ev_fill1) (void)hipEventDestroy(b->ev_fill1);
   if (b->ev_tr0) (void)hipEventDestroy(b->ev_tr0);
@@ -112,8 +115,8 @@ int batch_build(pw_batch* b) {
   }
   pw::plan_rules(b->mode, b->type, &b->brule, &b->endrule);
   b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
-  // ---- per-pair plans ----
-  int64_t maxspan = 0;
+  // ---- pass 1: per-pair plans (dptable_init arithmetic) and batch statistics ----
+  int64_t maxspan = 0, maxmin = 0; int maxnd = 0; int64_t sumnd = 0; int nsolv = 0;
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
   for (int32_t k = 0; k < b->n; k++) {
@@ -134,56 +137,93 @@ int batch_build(pw_batch* b) {
     d.tx_cap = p.origin_len + p.mutant_len + 1;
     tx_bytes += ((uint64_t)d.tx_cap + 15) / 16 * 16;
     if (d.solvable) {
-      const int bk = pw::plan_pick_bk(pl.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
-      if (bk == 0) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); tiled kernel not built yet",
-                 (int)k, pl.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
-        return fail(msg);
-      }
       d.dmin = pl.dmin; d.ndiag = pl.ndiag; d.s0 = pl.s0; d.nblocks = pl.nblocks;
       d.steady_b0 = pl.steady_b0; d.steady_b1 = pl.steady_b1;
-      d.bk = bk;
-      d.mask_off = mask_words;
-      mask_words += (uint64_t)pl.nblocks * 64 * bk;
       d.h_pitch = std::min(p.origin_len, p.mutant_len) + 1;
-      d.h_off = h_elems;
-      if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)pl.ndiag * d.h_pitch;
       b->cells += pl.cells;
       b->alg_bytes += pl.cells / 2 + p.origin_len + p.mutant_len + 32;
       maxspan = std::max<int64_t>(maxspan, (int64_t)p.origin_len + p.mutant_len + 2);
-      size_t ci = 0;
-      for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk) break;
-      if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; }
-      b->classes[ci].order.push_back(k);
+      maxmin = std::max<int64_t>(maxmin, std::min(p.origin_len, p.mutant_len));
+      maxnd = std::max(maxnd, pl.ndiag); sumnd += pl.ndiag; nsolv++;
     }
     b->descs[k] = d;
   }
+  // ---- score type and kernel variant ----
   // int32 is exact iff every score is an integer and no partial sum can leave +-2^27 (pw_wave.h)
   b->use_f64 = (b->flags & PW_FLAG_FORCE_F64) || !integral || (double)maxspan * maxabs >= (double)(1 << 27);
   const bool bany = b->brule == pw::BRULE_ANY;
   const bool track = b->endrule == pw::END_STD_LOCAL || b->endrule == pw::END_BANDED_LOCAL;
   if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || !b->simple || b->go > 0) b->variant = pw::VAR_GENERIC;
-  else if (bany) {
-    b->variant = pw::VAR_FAST_ANY_TRACK;
-    // packed 16-bit steady phase (pw_wave.h, WaveFill16): every running value must fit comfortably
-    int64_t maxmin = 0, maxspan16 = 0; int minbk = 1 << 30;
-    for (int32_t k = 0; k < b->n; k++) if (b->descs[k].solvable) {
-      maxmin = std::max<int64_t>(maxmin, std::min(b->pairs[k].origin_len, b->pairs[k].mutant_len));
-      maxspan16 = std::max<int64_t>(maxspan16, (int64_t)b->pairs[k].origin_len + b->pairs[k].mutant_len + 2);
-      minbk = std::min(minbk, (int)b->descs[k].bk);
-    }
-    const double mtc = std::max(mt, 0.0);
-    if (!b->use_f64 && track && !(b->flags & PW_FLAG_NO_PACKED16) && maxabs <= 100 && maxmin * mtc <= 16000 &&
-        maxspan16 < 32000 && minbk >= 4)
-      b->variant = pw::VAR_FAST16;
-  }
+  else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
+  // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16
+  int pbk = 0, pnl = 0;
+  if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 && !(b->flags & PW_FLAG_NO_PACKED16) &&
+      nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 16000 && maxspan < 32000 && b->ge <= 0) {
+    // diagonals per lane: the value that keeps most of the 64 x BK diagonal slots of a wave busy
+    const char* forced = getenv("PWLIB_PACKED_BK");
+    double best_util = -1;
+    for (int i = 0; i < pw::kNumPackedBK; i++) {
+      const int bk = pw::kPackedBK[i];
+      if (forced && atoi(forced) != bk) continue;
+      const int nl = (maxnd + bk - 1) / bk;
+      if (nl > 64) continue;
+      const int ppw = 64 / nl;
+      const double util = (double)ppw * ((double)sumnd / nsolv) / (64.0 * bk);
+      if (util >= best_util - 1e-9) { best_util = util; pbk = bk; pnl = nl; }   // ties: the larger BK
+    }
+    if (pbk) b->variant = pw::VAR_FAST16;
+  }
+  // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
+  for (int32_t k = 0; k < b->n; k++) {
+    pw::PairDesc& d = b->descs[k];
+    if (!d.solvable) continue;
+    int bk, nl;
+    if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
+    else {
+      bk = pw::plan_pick_bk(d.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
+      nl = 64;
+      if (bk == 0) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); tiled kernel not built yet",
+                 (int)k, d.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
+        return fail(msg);
+      }
+    }
+    d.bk = bk; d.nl = nl;
+    d.mask_off = mask_words;
+    mask_words += (uint64_t)d.nblocks * nl * bk;
+    d.h_off = h_elems;
+    if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)d.ndiag * d.h_pitch;
+    size_t ci = 0;
+    for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk) break;
+    if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; }
+    b->classes[ci].order.push_back(k);
+  }
   for (auto& c : b->classes)
     std::stable_sort(c.order.begin(), c.order.end(), [&](int32_t x, int32_t y) {
       return b->descs[x].nblocks > b->descs[y].nblocks;
     });
+  if (b->variant == pw::VAR_FAST16) {
+    // consecutive (similar length) pairs share a wavefront
+    const int ppw = 64 / pnl;
+    BkClass& c = b->classes[0];
+    for (size_t i = 0; i < c.order.size(); i += ppw) {
+      pw::WaveDesc wd;
+      memset(&wd, 0, sizeof wd);
+      wd.first = (int32_t)i; wd.count = (int32_t)std::min<size_t>(ppw, c.order.size() - i); wd.nl = pnl;
+      wd.nblocks = 0; wd.steady_b0 = 0; wd.steady_b1 = 0x7fffffff;
+      for (int q = 0; q < wd.count; q++) {
+        const pw::PairDesc& d = b->descs[c.order[i + q]];
+        wd.nblocks = std::max(wd.nblocks, d.nblocks);
+        wd.steady_b0 = std::max(wd.steady_b0, d.steady_b0);
+        wd.steady_b1 = std::min(wd.steady_b1, d.steady_b1);
+      }
+      if (wd.steady_b1 < wd.steady_b0) wd.steady_b1 = wd.steady_b0;
+      b->waves.push_back(wd);
+    }
+  }
   // ---- device buffers ----
   HIP_TRY(hipSetDevice(b->device));
   b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
@@ -203,6 +243,10 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipMemcpy(b->d_subst, si.data(), 4 * si.size(), hipMemcpyHostToDevice));
   }
   if (b->n) HIP_TRY(hipMemcpy(b->d_pairs, b->descs.data(), sizeof(pw::PairDesc) * b->n, hipMemcpyHostToDevice));
+  if (!b->waves.empty()) {
+    HIP_TRY(hipMalloc((void**)&b->d_waves, sizeof(pw::WaveDesc) * b->waves.size()));
+    HIP_TRY(hipMemcpy(b->d_waves, b->waves.data(), sizeof(pw::WaveDesc) * b->waves.size(), hipMemcpyHostToDevice));
+  }
   for (auto& c : b->classes) {
     HIP_TRY(hipMalloc((void**)&c.d_order, 4 * c.order.size()));
     HIP_TRY(hipMemcpy(c.d_order, c.order.data(), 4 * c.order.size(), hipMemcpyHostToDevice));
@@ -233,6 +277,19 @@ int launch_all_fills(pw_batch* b, hipStream_t st) {
     a.order = c.d_order;
     HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
   }
+  return 0;
+}
+
+int launch_packed_fill(pw_batch* b, hipStream_t st) {
+  pw::FillParams<int32_t> a;
+  memset(&a, 0, sizeof a);
+  a.pairs = b->d_pairs; a.arena = b->d_arena; a.masks = b->d_masks; a.results = b->d_results;
+  a.npairs = b->n; a.L = b->L; a.brule = b->brule; a.endrule = b->endrule;
+  a.banded = b->mode == pw::BANDED_MODE;
+  a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
+  a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
+  a.order = b->classes[0].d_order; a.waves = b->d_waves;
+  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, (int)b->waves.size(), st));
   return 0;
 }
 
@@ -313,7 +370,8 @@ int pw_batch_solve(pw_batch* b, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(b->device));
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_fill0, st));
-  const int rc = b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
+  const int rc = b->variant == pw::VAR_FAST16 ? launch_packed_fill(b, st)
+                 : b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
   if (rc != 0) return rc;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_fill1, st)); b->fill_timed = true; }
   return 0;

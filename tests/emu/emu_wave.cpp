@@ -95,10 +95,14 @@ template <typename T, int BK> struct Run16 {
 template <int BK> struct Run16<int32_t, BK> {
   static bool go(const pw::FillParams<int32_t>& a, const pw::PairDesc& pd) {
     if constexpr (BK % 4 == 0) {
+      // one pair in the wave, but on nl < 64 lanes: exercises the pair-boundary overrides of the lane-packed kernel
+      pw::WaveDesc wd;
+      memset(&wd, 0, sizeof wd);
+      wd.first = 0; wd.count = 1; wd.nblocks = pd.nblocks; wd.steady_b0 = pd.steady_b0; wd.steady_b1 = pd.steady_b1;
+      wd.nl = pd.nl;
       Emu emu;
       emu.run([&]() {
-        pw::WaveFill16<EmuP, BK> w(a, pd);
-        w.w.pair_slot = 0;
+        pw::WaveFill16<EmuP, BK> w(a, wd);
         w.run();
       });
       return true;
@@ -111,7 +115,7 @@ template <int BK> struct Run16<int32_t, BK> {
 template <typename T, int BK>
 void dispatch_variant(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst, int generic,
                       int bany, int track, int packed16) {
-  if (packed16 && !generic && bany && Run16<T, BK>::go(a, pd)) return;
+  if (packed16 && Run16<T, BK>::go(a, pd)) return;
   if (generic) run_fill<T, BK, false, true, true>(a, pd, subst);
   else if (bany && track) run_fill<T, BK, true, true, false>(a, pd, subst);
   else if (!bany && track) run_fill<T, BK, false, true, false>(a, pd, subst);
@@ -142,6 +146,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   pd.nblocks = pl.nblocks; pd.steady_b0 = pl.steady_b0; pd.steady_b1 = pl.steady_b1;
   pd.h_pitch = (X < Y ? X : Y) + 1;
   pd.tx_cap = X + Y + 1; pd.bk = bk; pd.solvable = 1;
+  pd.nl = 64;
   std::vector<uint32_t> masks((size_t)pl.nblocks * 64 * bk + 64, 0xdeadbeefu);   // + slack like the product
   std::vector<T> hd;
   if (hdump) hd.assign((size_t)pl.ndiag * pd.h_pitch, T(0));
@@ -162,12 +167,14 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   const int generic = force_generic || !simple || go > 0 || hdump != nullptr;
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
+  const int use16 = packed16 && !generic && bany && track && bk % 4 == 0 && sizeof(T) == 4;
+  if (use16) pd.nl = (pl.ndiag + bk - 1) / bk;
   switch (bk) {
-    case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, packed16); break;
-    case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track, packed16); break;
-    case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track, packed16); break;
-    case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track, packed16); break;
-    case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track, packed16); break;
+    case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, use16); break;
+    case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track, use16); break;
+    case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track, use16); break;
+    case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track, use16); break;
+    case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track, use16); break;
     default: return -4;
   }
   // traceback by "one lane"
