@@ -418,6 +418,10 @@ struct WaveFill {
 // end anywhere: the end-cell search uses the tracked bests only), match/mismatch scoring, go <= 0, every
 // score within +-100, min(X,Y) * match <= 16000, X + Y + 2 < 32000 (steps as signed 16-bit).
 // =================================================================================================
+// 16-byte group of the mask plane; an 8-byte store at any byte address
+struct __attribute__((aligned(8))) U4 { uint32_t x, y, z, w; };
+struct __attribute__((packed)) PackedU64 { uint64_t v; };   // an 8-byte store at any byte address
+
 namespace pk {
 #if defined(__HIP_DEVICE_COMPILE__)
 // clang vector types: the backend selects v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16 / v_pk_min_u16 /
@@ -467,10 +471,25 @@ struct WaveFill16 {
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
+  static constexpr int UNR = BK <= 8 ? 4 : (BK <= 16 ? 2 : 1);   // iterations unrolled per loop trip
   static constexpr int32_t NEG16 = -8192;
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
-  using Base = WaveFill<P, int32_t, BK, true, true, false>;
-  Base w;                               // geometry, feeders, mask stores and the end-cell search are shared
+  using Base = WaveFill<P, int32_t, BK, true, true, false>;       // only its static feeder helpers are used
+
+  // Lane packing: a wavefront holds `count` pairs side by side, `nl` lanes each (WaveDesc).  Everything
+  // that is per pair is therefore per LANE here (pd is a per-lane copy); the DPP wave shifts still move
+  // whole-wave, so the values that cross a pair boundary are replaced on the first / last lane of every
+  // pair (sentinel offers, or the pair's own sequence feeder).
+  const FillParams<int32_t>& a;
+  const WaveDesc wd;
+  PairDesc pd;
+  int li;                               // lane within the pair
+  bool valid, segfirst, seglast;
+  int pair_slot;
+  const uint8_t* oseq;
+  const uint8_t* mseq;
+  int X, Y, ndiag, owlast, mwlast, xfeed_o, yfeed_m;
+  uint32_t fo_lo, fo_hi, fm_lo, fm_hi, fo_n0, fo_n1, fo_n2, fm_n0, fm_n1, fm_n2;
 
   // packed state: index p <-> even slots (2p, 2p + R) [E*] / odd slots (2p + 1, 2p + 1 + R) [O*]
   uint32_t HE[RH], UE[RH], LE[RH], HO[RH], UO[RH], LO[RH];
@@ -479,9 +498,9 @@ struct WaveFill16 {
   uint32_t tfE[RH], tfO[RH], tlE[RH], tlO[RH];          // first / last step of each diagonal
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
-  uint32_t ONE, NDELTA, MATCHV, GOV, NEGV, LIMV;
+  uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, NEGV, LIMV;
 
-  PW_FN WaveFill16(const FillParams<int32_t>& a, const PairDesc& pd) : w(a, pd, nullptr) {}
+  PW_FN WaveFill16(const FillParams<int32_t>& a_, const WaveDesc& wd_) : a(a_), wd(wd_) {}
 
   // Two cells at once.  `acc` collects the INVERTED tie bits (1 = candidate not kept), 4 bits per cell:
   // bit 0 B, bit 1 D, bit 2 I; bit 3 (M) stays 0 -- with go <= 0 the walker never needs it: the first
@@ -503,7 +522,7 @@ struct WaveFill16 {
     const uint32_t ne = pk::minu(oc ^ mc, ONE);                 // 0 where the letters match
     const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
     uint32_t Hn = pk::max(pk::max(up, left), hM);
-    if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf)) & NEGV);   // B = 0 once started, sentinel before
+    if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
     else Hn = pk::max(Hn, 0u);                                   // B: an alignment may begin anywhere, score 0
     const uint32_t nD = pk::minu(pk::sub(Hn, up), ONE);
     const uint32_t nI = pk::minu(pk::sub(Hn, left), ONE);
@@ -511,9 +530,9 @@ struct WaveFill16 {
     const uint32_t hg = pk::add(Hn, geb);
     Us = pk::mad(nD, GOV, hg);                                   // (H + ge) + go unless a D choice is kept
     Ls = pk::mad(nI, GOV, hg);
-    // halves hold values <= 7: plain 32-bit shift-adds never carry across the halves
-    acc = (acc << 4) + (((nI << 2) + (nD << 1)) + nB);
-    const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv)) & LIMV) : Hn;
+    // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
+    acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
+    const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV) : Hn;
     const uint32_t bn = pk::max(bests, Ht);
     const uint32_t u = pk::minu(pk::sub(bn, bests), ONE);       // 1 where the best strictly improved
     bts = pk::mad(u, pk::sub(tv, bts), bts);
@@ -521,23 +540,29 @@ struct WaveFill16 {
     Hs = Hn;
   }
 
-  template <bool EDGE>
+  // HALF selects the accumulator set: iterations 0-3 of a block (cells 0-3 of every slot) or 4-7.
+  template <bool EDGE, int HALF>
   PW_FN void iteration16(int it, int k) {
     const uint32_t tv0 = pk::both(2 * it), tv1 = pk::both(2 * it + 1);
     // even step: slot 0 <- previous lane's last slot, slot R <- own slot R - 1
     {
-      const uint32_t prev = xshr1<P>(UO[RH - 1], NEGV);
+      uint32_t prev = xshr1<P>(UO[RH - 1], NEGV);
+      prev = segfirst ? NEGV : prev;
       const uint32_t up0 = pk::align16(UO[RH - 1], prev);         // (prev.hi, own.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
-        cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], k < 4 ? accE[p] : acc2E[p],
+        cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
                        p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0);
     }
-    // origin window moves on: last register <- (own first.hi, next lane's first.lo | feeder)
+    // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
+    // Only cells outside the table read letters outside a sequence; in steady blocks those are out-of-band
+    // slots whose values nobody reads, so the range check is needed in EDGE blocks only.
     {
-      const int oi = w.xfeed_o + it;
-      const uint32_t feed = (uint32_t)oi < (uint32_t)w.X ? Base::feed_byte(w.fo_lo, w.fo_hi, k) : SENT_O;
-      const uint32_t nxt = xshl1<P>(OW[0], feed);
+      const int oi = xfeed_o + it;
+      const uint32_t fb = Base::feed_byte(fo_lo, fo_hi, k);
+      const uint32_t feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? fb : SENT_O;
+      uint32_t nxt = xshl1<P>(OW[0], feed);
+      nxt = seglast ? feed : nxt;
       const uint32_t last = pk::align16(nxt, OW[0]);
 #pragma unroll
       for (int p = 0; p + 1 < RH; p++) OW[p] = OW[p + 1];
@@ -545,18 +570,21 @@ struct WaveFill16 {
     }
     // odd step: slot BK - 1 <- next lane's slot 0, slot R - 1 <- own slot R
     {
-      const uint32_t nxt = xshl1<P>(LE[0], NEGV);
+      uint32_t nxt = xshl1<P>(LE[0], NEGV);
+      nxt = seglast ? NEGV : nxt;
       const uint32_t leftl = pk::align16(nxt, LE[0]);              // (own.hi, next.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
-        cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], k < 4 ? accO[p] : acc2O[p],
+        cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
                        UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1);
     }
-    // mutant window moves on: first register <- (previous lane's last.hi | feeder, own last.lo)
+    // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
     {
-      const int mi = w.yfeed_m + it;
-      const uint32_t feed = ((uint32_t)mi < (uint32_t)w.Y ? Base::feed_byte(w.fm_lo, w.fm_hi, k) : SENT_M) << 16;
-      const uint32_t prv = xshr1<P>(MW[RH - 1], feed);
+      const int mi = yfeed_m + it;
+      const uint32_t fbm = Base::feed_byte(fm_lo, fm_hi, k);
+      const uint32_t feed = ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? fbm : SENT_M) << 16;
+      uint32_t prv = xshr1<P>(MW[RH - 1], feed);
+      prv = segfirst ? feed : prv;
       const uint32_t first = pk::align16(MW[RH - 1], prv);
 #pragma unroll
       for (int p = RH - 1; p > 0; p--) MW[p] = MW[p - 1];
@@ -568,66 +596,159 @@ struct WaveFill16 {
   PW_FN void block16(int b) {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
+    // unroll depth: full for narrow lanes (the letter-window shifts become register renames), shallower for
+    // wide ones, where the live state already fills the register file
+#pragma unroll(UNR)
+    for (int k = 0; k < 4; k++) iteration16<EDGE, 0>(8 * b + k, k);
+#pragma unroll(UNR)
+    for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
+    // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept).
+    // Slots are gathered into their natural order so that every group of 4 goes out as one 16-byte store.
+    if (valid && li * BK < ndiag && b < pd.nblocks) {
+      uint32_t mwd[BK];
 #pragma unroll
-    for (int k = 0; k < 8; k++) iteration16<EDGE>(8 * b + k, k);
-    // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept)
+      for (int p = 0; p < RH; p++) {
+        mwd[2 * p] = 0x77777777u - (((accE[p] & 0xffffu) << 16) | (acc2E[p] & 0xffffu));
+        mwd[2 * p + R] = 0x77777777u - ((accE[p] & 0xffff0000u) | (acc2E[p] >> 16));
+        mwd[2 * p + 1] = 0x77777777u - (((accO[p] & 0xffffu) << 16) | (acc2O[p] & 0xffffu));
+        mwd[2 * p + 1 + R] = 0x77777777u - ((accO[p] & 0xffff0000u) | (acc2O[p] >> 16));
+      }
+      uint32_t* dst = a.masks + pd.mask_off;
 #pragma unroll
-    for (int p = 0; p < RH; p++) {
-      w.m[2 * p] = 0x77777777u - (((accE[p] & 0xffffu) << 16) | (acc2E[p] & 0xffffu));
-      w.m[2 * p + R] = 0x77777777u - ((accE[p] & 0xffff0000u) | (acc2E[p] >> 16));
-      w.m[2 * p + 1] = 0x77777777u - (((accO[p] & 0xffffu) << 16) | (acc2O[p] & 0xffffu));
-      w.m[2 * p + 1 + R] = 0x77777777u - ((accO[p] & 0xffff0000u) | (acc2O[p] >> 16));
+      for (int g = 0; g < BK / 4; g++) {
+        U4 v; v.x = mwd[4 * g]; v.y = mwd[4 * g + 1]; v.z = mwd[4 * g + 2]; v.w = mwd[4 * g + 3];
+        *(U4*)(dst + mask_word_index(BK, pd.nl, b, li, 4 * g)) = v;
+      }
     }
   }
 
+  PW_FN void feed_issue(int b) {
+    const uint32_t* o32 = (const uint32_t*)oseq;
+    const uint32_t* m32 = (const uint32_t*)mseq;
+    const int wo = (xfeed_o + 8 * b) >> 2, wm = (yfeed_m + 8 * b) >> 2;
+    fo_n0 = o32[pw_clampi(wo, 0, owlast)]; fo_n1 = o32[pw_clampi(wo + 1, 0, owlast)]; fo_n2 = o32[pw_clampi(wo + 2, 0, owlast)];
+    fm_n0 = m32[pw_clampi(wm, 0, mwlast)]; fm_n1 = m32[pw_clampi(wm + 1, 0, mwlast)]; fm_n2 = m32[pw_clampi(wm + 2, 0, mwlast)];
+  }
+  PW_FN void feed_commit(int b) {
+    const int ro = (xfeed_o + 8 * b) & 3, rm = (yfeed_m + 8 * b) & 3;
+    fo_lo = Base::funnel(fo_n1, fo_n0, ro); fo_hi = Base::funnel(fo_n2, fo_n1, ro);
+    fm_lo = Base::funnel(fm_n1, fm_n0, rm); fm_hi = Base::funnel(fm_n2, fm_n1, rm);
+  }
+
   PW_FN int tfirst_of(int j) const {      // first step of slot j's diagonal; never for a diagonal outside the band
-    const int dd = w.lane * BK + j, d = w.pd.dmin + dd;
-    return dd < w.ndiag ? (d < 0 ? -d : d) - w.pd.s0 : 32767;
+    const int dd = li * BK + j, d = pd.dmin + dd;
+    return (valid && dd < ndiag) ? (d < 0 ? -d : d) - pd.s0 : 32767;
   }
   PW_FN int tlast_of(int j) const {
-    const int dd = w.lane * BK + j, d = w.pd.dmin + dd;
-    if (dd >= w.ndiag) return -1;
-    const int len = 1 + (d > 0 ? 0 : d) + (w.X - d > w.Y ? w.Y : w.X - d);
-    return (d < 0 ? -d : d) - w.pd.s0 + 2 * (len - 1);
+    const int dd = li * BK + j, d = pd.dmin + dd;
+    if (!valid || dd >= ndiag) return -1;
+    const int len = 1 + (d > 0 ? 0 : d) + (X - d > Y ? Y : X - d);
+    return (d < 0 ? -d : d) - pd.s0 + 2 * (len - 1);
   }
-  PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)w.X ? (uint32_t)w.oseq[i] : SENT_O; }
-  PW_FN uint32_t letter_m(int i) const { return (uint32_t)i < (uint32_t)w.Y ? (uint32_t)w.mseq[i] : SENT_M; }
+  PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)X ? (uint32_t)oseq[i] : SENT_O; }
+  PW_FN uint32_t letter_m(int i) const { return (uint32_t)i < (uint32_t)Y ? (uint32_t)mseq[i] : SENT_M; }
+  PW_FN int blocked(int j) const { return li * BK + j == ndiag ? NEG16 : 0; }   // first diagonal above the band
 
   PW_FN void run() {
-    w.init();
-    const FillParams<int32_t>& a = w.a;
-    ONE = 0x00010001u; NEGV = pk::both(NEG16); LIMV = pk::both(-32767);
+    const int lane = P::lane();
+    const int nl = wd.nl;
+    const int seg = lane / nl;
+    li = lane - seg * nl;
+    valid = seg < wd.count;
+    segfirst = li == 0; seglast = li == nl - 1;
+    const int slot = wd.first + (valid ? seg : 0);          // lanes beyond the last pair shadow the first one
+    pair_slot = a.order ? a.order[slot] : slot;
+    pd = a.pairs[pair_slot];
+    X = pd.X; Y = pd.Y; ndiag = pd.ndiag;
+    oseq = a.arena + pd.o_off; mseq = a.arena + pd.m_off;
+    owlast = (X > 0 ? X - 1 : 0) >> 2; mwlast = (Y > 0 ? Y - 1 : 0) >> 2;
+    const int e = (pd.s0 + pd.dmin) >> 1;       // x of diagonal dd = 0 on step t = 0 (s0 == dmin mod 2)
+    const int f = (pd.s0 - pd.dmin) >> 1;       // y likewise
+    const int xbase = e + li * R, ybase = f - li * R;
+    xfeed_o = e + nl * R - 1;                   // the letter a virtual lane `nl` would hand down
+    yfeed_m = f;
+    ONE = pk::opaque(0x00010001u); SH15 = pk::opaque(0x000f000fu);
+    C2 = pk::opaque(0x00020002u); C4 = pk::opaque(0x00040004u); C16 = pk::opaque(0x00100010u);
+    NEGV = pk::both(NEG16); LIMV = pk::both(-32767);
     NDELTA = pk::both(a.mismatch - a.match); MATCHV = pk::both(a.match); GOV = pk::both(a.go);
 #pragma unroll
     for (int p = 0; p < RH; p++) {
       const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      gebE[p] = pk::pack(a.ge + (w.blkL[e0] ? NEG16 : 0), a.ge + (w.blkL[e1] ? NEG16 : 0));
-      gebO[p] = pk::pack(a.ge + (w.blkL[o0] ? NEG16 : 0), a.ge + (w.blkL[o1] ? NEG16 : 0));
+      gebE[p] = pk::pack(a.ge + blocked(e0), a.ge + blocked(e1));
+      gebO[p] = pk::pack(a.ge + blocked(o0), a.ge + blocked(o1));
       tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
       tlE[p] = pk::pack(tlast_of(e0), tlast_of(e1)); tlO[p] = pk::pack(tlast_of(o0), tlast_of(o1));
       HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
       bestE[p] = bestO[p] = NEGV; btE[p] = btO[p] = 0;
-      OW[p] = pk::pack((int32_t)letter_o(w.xbase + p - 1), (int32_t)letter_o(w.xbase + p + RH - 1));
-      MW[p] = pk::pack((int32_t)letter_m(w.ybase - p - 1), (int32_t)letter_m(w.ybase - p - RH - 1));
+      OW[p] = pk::pack((int32_t)letter_o(xbase + p - 1), (int32_t)letter_o(xbase + p + RH - 1));
+      MW[p] = pk::pack((int32_t)letter_m(ybase - p - 1), (int32_t)letter_m(ybase - p - RH - 1));
     }
-    w.feed_issue(0);
-    for (int b = 0; b < w.pd.nblocks; b++) {
-      w.feed_commit(b);
-      if (b + 1 < w.pd.nblocks) w.feed_issue(b + 1);
-      if (b >= w.pd.steady_b0 && b < w.pd.steady_b1) block16<false>(b);
+    feed_issue(0);
+    for (int b = 0; b < wd.nblocks; b++) {
+      feed_commit(b);
+      if (b + 1 < wd.nblocks) feed_issue(b + 1);
+      if (b >= wd.steady_b0 && b < wd.steady_b1) block16<false>(b);
       else block16<true>(b);
-      w.store_masks(b);
     }
-    // hand the per-diagonal bests to the shared end-cell search
+    finish();
+  }
+
+  // End-cell search for the two rules this kernel serves (END_STD_LOCAL, END_BANDED_LOCAL): the first best
+  // cell of every in-band diagonal, reduced on (score desc, scan rank asc) -- once per pair of the wave.
+  PW_FN void finish() {
+    const int endrule = a.endrule;
+    int32_t cs = NEG16 - 1; uint64_t ck = ~(uint64_t)0; int cx = -1, cy = -1; bool have = false;
+    // Runs once per pair: keep it out of the register budget of the fill loop.  The packed bests are parked
+    // in a small private array and scanned by a rolled loop.
+    uint32_t parked[4 * RH];
 #pragma unroll
     for (int p = 0; p < RH; p++) {
-      const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      w.best[e0] = pk::lo_s(bestE[p]); w.best[e1] = pk::hi_s(bestE[p]);
-      w.best[o0] = pk::lo_s(bestO[p]); w.best[o1] = pk::hi_s(bestO[p]);
-      w.bestT[e0] = (int32_t)(btE[p] & 0xffffu); w.bestT[e1] = (int32_t)(btE[p] >> 16);
-      w.bestT[o0] = (int32_t)(btO[p] & 0xffffu); w.bestT[o1] = (int32_t)(btO[p] >> 16);
+      parked[4 * p] = bestE[p]; parked[4 * p + 1] = btE[p]; parked[4 * p + 2] = bestO[p]; parked[4 * p + 3] = btO[p];
     }
-    w.finish();
+#pragma unroll 1
+    for (int q = 0; q < 2 * RH; q++) {
+      const int p = q >> 1, odd = q & 1;
+      const uint32_t bq = parked[4 * p + 2 * odd], tq = parked[4 * p + 2 * odd + 1];
+#pragma unroll 1
+      for (int h = 0; h < 2; h++) {
+        const int j = 2 * p + odd + h * R;
+        const int dd = li * BK + j, d = pd.dmin + dd;
+        const int32_t s = h ? pk::hi_s(bq) : pk::lo_s(bq);
+        const int bt = (int)(h ? (tq >> 16) : (tq & 0xffffu));
+        const int tfirst = (d < 0 ? -d : d) - pd.s0;
+        const int aa = (bt - tfirst) >> 1;
+        const int x = aa + (d > 0 ? d : 0), y = aa - (d < 0 ? d : 0);
+        uint64_t k;
+        if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
+        else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
+        const bool better = valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));
+        if (better) { cs = s; ck = k; cx = x; cy = y; have = true; }
+      }
+    }
+    const int lane = P::lane();
+    const int seg = lane / wd.nl;
+    for (int sidx = 0; sidx < wd.count; sidx++) {
+      int hv = (have && seg == sidx) ? 1 : 0;
+      int32_t rs = cs; uint64_t rk = ck; int rx = cx, ry = cy;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const int32_t os = P::shfl_xor(rs, off);
+        const uint64_t ok_ = xshfl_xor<P>(rk, off);
+        const int ox = P::shfl_xor(rx, off), oy = P::shfl_xor(ry, off), oh = P::shfl_xor(hv, off);
+        const bool take = oh && (!hv || os > rs || (os == rs && ok_ < rk));
+        if (take) { rs = os; rk = ok_; rx = ox; ry = oy; hv = 1; }
+      }
+      if (seg == sidx && li == 0) {
+        Result r;
+        r.score = (double)rs;
+        r.opt_i = a.banded ? rx - ry - pd.dmin : rx;
+        r.opt_j = a.banded ? (rx < ry ? rx : ry) : ry;
+        r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;
+        // LOCAL starts from the score of cell (0,0), i.e. 0 (_pw_internals.c:342)
+        if (!hv || (endrule == END_STD_LOCAL && !(rs > 0))) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; }
+        a.results[pair_slot] = r;
+      }
+    }
   }
 };
 
@@ -641,8 +762,6 @@ PW_FN int pw_first_op(uint32_t mask) {   // index of the lowest set bit: 0 B, 1 
   return (mask & 1u) ? 0 : (mask & 2u) ? 1 : (mask & 4u) ? 2 : 3;
 }
 
-struct __attribute__((aligned(8))) U4 { uint32_t x, y, z, w; };
-struct __attribute__((packed)) PackedU64 { uint64_t v; };   // an 8-byte store at any byte address
 
 // ---- K4a: the walk --------------------------------------------------------------------------------
 // One lane walks one pair; a wavefront holds 64 walkers.  The walk is a chain of dependent steps, and
