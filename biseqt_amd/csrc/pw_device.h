@@ -29,6 +29,7 @@ struct DevP {
     return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   }
   PW_FN static int32_t shfl_xor(int32_t v, int m) { return __shfl_xor(v, m, 64); }
+  PW_FN static int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 };
 
 constexpr int kMaxLdsL = 32;   // substitution tables up to 32 x 32 are staged in LDS
@@ -56,10 +57,10 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
 }
 
 // Lane-packed 16-bit kernel: one wavefront = WaveDesc.count pairs side by side (pw_wave.h, WaveFill16).
-template <int BK>
+template <int BK, bool SEG>
 __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int32_t> a) {
   const WaveDesc wd = a.waves[blockIdx.x];
-  WaveFill16<DevP, BK> w(a, wd);
+  WaveFill16<DevP, BK, SEG> w(a, wd);
   w.run();
 }
 

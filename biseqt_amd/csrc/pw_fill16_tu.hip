@@ -6,8 +6,9 @@
 #define PW_CAT(a, b) PW_CAT2(a, b)
 
 namespace pw {
-hipError_t PW_CAT(launch_fill16_bk, PW_BK)(const FillParams<int32_t>& a, int nwaves, hipStream_t st) {
-  hipLaunchKernelGGL((k_fill16<PW_BK>), dim3((unsigned)nwaves), dim3(64), 0, st, a);
+hipError_t PW_CAT(launch_fill16_bk, PW_BK)(const FillParams<int32_t>& a, int seg, int nwaves, hipStream_t st) {
+  if (seg) hipLaunchKernelGGL((k_fill16<PW_BK, true>), dim3((unsigned)nwaves), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((k_fill16<PW_BK, false>), dim3((unsigned)nwaves), dim3(64), 0, st, a);
   return hipGetLastError();
 }
 }  // namespace pw

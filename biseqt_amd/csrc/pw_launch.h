@@ -23,7 +23,8 @@ hipError_t launch_fill(const FillParams<double>& a, int variant, int bk, int nbl
 // lane-packed 16-bit kernel (VAR_FAST16): one block per WaveDesc
 static const int kPackedBK[] = {4, 8, 12, 16, 20, 24, 28, 32};
 static const int kNumPackedBK = 8;
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int nwaves, hipStream_t st);
+// seg != 0: several pairs per wavefront (WaveDesc.nl lanes each); seg == 0: one pair per wavefront, WaveDesc.nl == 64
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
 
 }  // namespace pw

@@ -66,20 +66,20 @@ hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
 PW_DECL(i32, int32_t)
 PW_DECL(f64, double)
 #undef PW_DECL
-#define PW_DECL16(BK) hipError_t launch_fill16_bk##BK(const FillParams<int32_t>&, int, hipStream_t);
+#define PW_DECL16(BK) hipError_t launch_fill16_bk##BK(const FillParams<int32_t>&, int, int, hipStream_t);
 PW_DECL16(4) PW_DECL16(8) PW_DECL16(12) PW_DECL16(16) PW_DECL16(20) PW_DECL16(24) PW_DECL16(28) PW_DECL16(32)
 #undef PW_DECL16
 
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int nwaves, hipStream_t st) {
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st) {
   switch (bk) {
-    case 4: return launch_fill16_bk4(a, nwaves, st);
-    case 8: return launch_fill16_bk8(a, nwaves, st);
-    case 12: return launch_fill16_bk12(a, nwaves, st);
-    case 16: return launch_fill16_bk16(a, nwaves, st);
-    case 20: return launch_fill16_bk20(a, nwaves, st);
-    case 24: return launch_fill16_bk24(a, nwaves, st);
-    case 28: return launch_fill16_bk28(a, nwaves, st);
-    case 32: return launch_fill16_bk32(a, nwaves, st);
+    case 4: return launch_fill16_bk4(a, seg, nwaves, st);
+    case 8: return launch_fill16_bk8(a, seg, nwaves, st);
+    case 12: return launch_fill16_bk12(a, seg, nwaves, st);
+    case 16: return launch_fill16_bk16(a, seg, nwaves, st);
+    case 20: return launch_fill16_bk20(a, seg, nwaves, st);
+    case 24: return launch_fill16_bk24(a, seg, nwaves, st);
+    case 28: return launch_fill16_bk28(a, seg, nwaves, st);
+    case 32: return launch_fill16_bk32(a, seg, nwaves, st);
     default: return hipErrorInvalidValue;
   }
 }

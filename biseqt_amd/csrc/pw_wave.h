@@ -466,7 +466,7 @@ PW_FN int32_t lo_s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffffu); }
 PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 }  // namespace pk
 
-template <class P, int BK>
+template <class P, int BK, bool SEG>
 struct WaveFill16 {
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
@@ -476,10 +476,12 @@ struct WaveFill16 {
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
   using Base = WaveFill<P, int32_t, BK, true, true, false>;       // only its static feeder helpers are used
 
-  // Lane packing: a wavefront holds `count` pairs side by side, `nl` lanes each (WaveDesc).  Everything
-  // that is per pair is therefore per LANE here (pd is a per-lane copy); the DPP wave shifts still move
+  // SEG = true, lane packing: a wavefront holds `count` pairs side by side, `nl` lanes each (WaveDesc).
+  // Everything that is per pair is then per LANE (pd is a per-lane copy); the DPP wave shifts still move
   // whole-wave, so the values that cross a pair boundary are replaced on the first / last lane of every
   // pair (sentinel offers, or the pair's own sequence feeder).
+  // SEG = false: one pair per wavefront (wd.nl == 64); the descriptor is wave-uniform (scalar registers and
+  // scalar loads) and the DPP `old` operand alone handles the two wave edges.
   const FillParams<int32_t>& a;
   const WaveDesc wd;
   PairDesc pd;
@@ -547,7 +549,7 @@ struct WaveFill16 {
     // even step: slot 0 <- previous lane's last slot, slot R <- own slot R - 1
     {
       uint32_t prev = xshr1<P>(UO[RH - 1], NEGV);
-      prev = segfirst ? NEGV : prev;
+      if (SEG) prev = segfirst ? NEGV : prev;
       const uint32_t up0 = pk::align16(UO[RH - 1], prev);         // (prev.hi, own.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
@@ -562,7 +564,7 @@ struct WaveFill16 {
       const uint32_t fb = Base::feed_byte(fo_lo, fo_hi, k);
       const uint32_t feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? fb : SENT_O;
       uint32_t nxt = xshl1<P>(OW[0], feed);
-      nxt = seglast ? feed : nxt;
+      if (SEG) nxt = seglast ? feed : nxt;
       const uint32_t last = pk::align16(nxt, OW[0]);
 #pragma unroll
       for (int p = 0; p + 1 < RH; p++) OW[p] = OW[p + 1];
@@ -571,7 +573,7 @@ struct WaveFill16 {
     // odd step: slot BK - 1 <- next lane's slot 0, slot R - 1 <- own slot R
     {
       uint32_t nxt = xshl1<P>(LE[0], NEGV);
-      nxt = seglast ? NEGV : nxt;
+      if (SEG) nxt = seglast ? NEGV : nxt;
       const uint32_t leftl = pk::align16(nxt, LE[0]);              // (own.hi, next.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
@@ -584,7 +586,7 @@ struct WaveFill16 {
       const uint32_t fbm = Base::feed_byte(fm_lo, fm_hi, k);
       const uint32_t feed = ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? fbm : SENT_M) << 16;
       uint32_t prv = xshr1<P>(MW[RH - 1], feed);
-      prv = segfirst ? feed : prv;
+      if (SEG) prv = segfirst ? feed : prv;
       const uint32_t first = pk::align16(MW[RH - 1], prv);
 #pragma unroll
       for (int p = RH - 1; p > 0; p--) MW[p] = MW[p - 1];
@@ -656,8 +658,9 @@ struct WaveFill16 {
     li = lane - seg * nl;
     valid = seg < wd.count;
     segfirst = li == 0; seglast = li == nl - 1;
-    const int slot = wd.first + (valid ? seg : 0);          // lanes beyond the last pair shadow the first one
+    const int slot = wd.first + ((SEG && valid) ? seg : 0);   // lanes beyond the last pair shadow the first one
     pair_slot = a.order ? a.order[slot] : slot;
+    if (!SEG) pair_slot = P::uniform(pair_slot);             // one pair: keep its descriptor in scalar registers
     pd = a.pairs[pair_slot];
     X = pd.X; Y = pd.Y; ndiag = pd.ndiag;
     oseq = a.arena + pd.o_off; mseq = a.arena + pd.m_off;

@@ -60,6 +60,7 @@ struct pw_batch {
   std::vector<pw::PairDesc> descs;
   std::vector<BkClass> classes;
   std::vector<pw::WaveDesc> waves;      // lane-packed kernel: one per wavefront
+  int packed_seg = 0;
   pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
   // device
@@ -158,21 +159,28 @@ int batch_build(pw_batch* b) {
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
   // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16
-  int pbk = 0, pnl = 0;
+  int pbk = 0, pnl = 0, pseg = 0;
   if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 && !(b->flags & PW_FLAG_NO_PACKED16) &&
       nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 16000 && maxspan < 32000 && b->ge <= 0) {
-    // diagonals per lane: the value that keeps most of the 64 x BK diagonal slots of a wave busy
-    const char* forced = getenv("PWLIB_PACKED_BK");
-    double best_util = -1;
+    // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
+    // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
+    // 64 x BK diagonal slots busy.  Packing is chosen when it buys at least 25 % more busy slots.
+    const char* forced = getenv("PWLIB_PACKED_BK");        // tuning / A-B: "<bk>" or "<bk>s" (force packing)
+    const double meannd = (double)sumnd / nsolv;
+    double util1 = -1, utilp = -1; int bk1 = 0, bkp = 0, nlp = 0;
     for (int i = 0; i < pw::kNumPackedBK; i++) {
       const int bk = pw::kPackedBK[i];
       if (forced && atoi(forced) != bk) continue;
       const int nl = (maxnd + bk - 1) / bk;
       if (nl > 64) continue;
-      const int ppw = 64 / nl;
-      const double util = (double)ppw * ((double)sumnd / nsolv) / (64.0 * bk);
-      if (util >= best_util - 1e-9) { best_util = util; pbk = bk; pnl = nl; }   // ties: the larger BK
+      const double u1 = meannd / (64.0 * bk);
+      if (u1 > util1 + 1e-9) { util1 = u1; bk1 = bk; }                       // smallest BK that fits
+      const double up = (double)(64 / nl) * meannd / (64.0 * bk);
+      if (64 / nl >= 2 && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
     }
+    const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
+    if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }
+    else if (bk1) { pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 0; }
     if (pbk) b->variant = pw::VAR_FAST16;
   }
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
@@ -207,12 +215,14 @@ int batch_build(pw_batch* b) {
     });
   if (b->variant == pw::VAR_FAST16) {
     // consecutive (similar length) pairs share a wavefront
-    const int ppw = 64 / pnl;
+    const int ppw = pseg ? 64 / pnl : 1;
+    b->packed_seg = pseg;
     BkClass& c = b->classes[0];
     for (size_t i = 0; i < c.order.size(); i += ppw) {
       pw::WaveDesc wd;
       memset(&wd, 0, sizeof wd);
-      wd.first = (int32_t)i; wd.count = (int32_t)std::min<size_t>(ppw, c.order.size() - i); wd.nl = pnl;
+      wd.first = (int32_t)i; wd.count = (int32_t)std::min<size_t>(ppw, c.order.size() - i);
+      wd.nl = pseg ? pnl : 64;      // lanes per pair in the wave (the mask plane rows stay pnl wide)
       wd.nblocks = 0; wd.steady_b0 = 0; wd.steady_b1 = 0x7fffffff;
       for (int q = 0; q < wd.count; q++) {
         const pw::PairDesc& d = b->descs[c.order[i + q]];
@@ -289,7 +299,7 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
   a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
   a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
   a.order = b->classes[0].d_order; a.waves = b->d_waves;
-  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, (int)b->waves.size(), st));
+  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, (int)b->waves.size(), st));
   return 0;
 }
 
@@ -348,7 +358,7 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; }
   const char* t = b->use_f64 ? "double" : "int";
   switch (b->variant) {
-    case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d>", bk); break;
+    case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false"); break;
     case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;
     case pw::VAR_FAST_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, false, true, false>", t, bk); break;
     case pw::VAR_FAST: snprintf(name, sizeof name, "k_fill<%s, %d, false, false, false>", t, bk); break;

@@ -77,6 +77,7 @@ struct EmuP {
   static int32_t shr1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur - 1, old); }
   static int32_t shl1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, old); }
   static int32_t shfl_xor(int32_t v, int m) { Emu* e = Emu::self; return e->exchange(v, e->cur ^ m, 0); }
+  static int32_t uniform(int32_t v) { return v; }
 };
 
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
@@ -89,6 +90,8 @@ void run_fill(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst
   });
 }
 
+int g_packed_mode = 0;
+
 template <typename T, int BK> struct Run16 {
   static bool go(const pw::FillParams<T>&, const pw::PairDesc&) { return false; }
 };
@@ -99,12 +102,12 @@ template <int BK> struct Run16<int32_t, BK> {
       pw::WaveDesc wd;
       memset(&wd, 0, sizeof wd);
       wd.first = 0; wd.count = 1; wd.nblocks = pd.nblocks; wd.steady_b0 = pd.steady_b0; wd.steady_b1 = pd.steady_b1;
-      wd.nl = pd.nl;
+      // packed16 == 1: lane-packed form on nl < 64 lanes; packed16 == 2: one pair per wave, uniform form
+      const bool seg = g_packed_mode == 1;
+      wd.nl = seg ? pd.nl : 64;
       Emu emu;
-      emu.run([&]() {
-        pw::WaveFill16<EmuP, BK> w(a, wd);
-        w.run();
-      });
+      if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true> w(a, wd); w.run(); });
+      else emu.run([&]() { pw::WaveFill16<EmuP, BK, false> w(a, wd); w.run(); });
       return true;
     } else {
       return false;
@@ -168,6 +171,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
   const int use16 = packed16 && !generic && bany && track && bk % 4 == 0 && sizeof(T) == 4;
+  g_packed_mode = packed16;
   if (use16) pd.nl = (pl.ndiag + bk - 1) / bk;
   switch (bk) {
     case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, use16); break;
