@@ -606,7 +606,12 @@ struct WaveFill16 {
     for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
     // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept).
     // Slots are gathered into their natural order so that every group of 4 goes out as one 16-byte store.
-    if (valid && li * BK < ndiag && b < pd.nblocks) {
+    // Lanes with nothing to store (padding lanes, lanes beyond the plane's rows, blocks past the pair's last)
+    // write into the plane's spare row (row `nblocks`, slot 0) instead of branching: a branch here splits the
+    // unrolled block and serialises the packed ops (dependent VOP3P ops need a wait state between them).
+    {
+      const bool st = valid && li < pd.nl && b < pd.nblocks;
+      const int bb = st ? b : pd.nblocks, ll = st ? li : 0;
       uint32_t mwd[BK];
 #pragma unroll
       for (int p = 0; p < RH; p++) {
@@ -619,7 +624,7 @@ struct WaveFill16 {
 #pragma unroll
       for (int g = 0; g < BK / 4; g++) {
         U4 v; v.x = mwd[4 * g]; v.y = mwd[4 * g + 1]; v.z = mwd[4 * g + 2]; v.w = mwd[4 * g + 3];
-        *(U4*)(dst + mask_word_index(BK, pd.nl, b, li, 4 * g)) = v;
+        *(U4*)(dst + mask_word_index(BK, pd.nl, bb, ll, 4 * g)) = v;
       }
     }
   }

@@ -201,7 +201,7 @@ int batch_build(pw_batch* b) {
     }
     d.bk = bk; d.nl = nl;
     d.mask_off = mask_words;
-    mask_words += (uint64_t)d.nblocks * nl * bk;
+    mask_words += (uint64_t)(d.nblocks + 1) * nl * bk;   // + one spare row: the branch-free stores of idle lanes land there
     d.h_off = h_elems;
     if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)d.ndiag * d.h_pitch;
     size_t ci = 0;

@@ -150,7 +150,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   pd.h_pitch = (X < Y ? X : Y) + 1;
   pd.tx_cap = X + Y + 1; pd.bk = bk; pd.solvable = 1;
   pd.nl = 64;
-  std::vector<uint32_t> masks((size_t)pl.nblocks * 64 * bk + 64, 0xdeadbeefu);   // + slack like the product
+  std::vector<uint32_t> masks((size_t)(pl.nblocks + 1) * 64 * bk + 64, 0xdeadbeefu);   // + spare row and slack like the product
   std::vector<T> hd;
   if (hdump) hd.assign((size_t)pl.ndiag * pd.h_pitch, T(0));
   std::vector<T> sub((size_t)L * L);
