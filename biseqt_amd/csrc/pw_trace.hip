@@ -10,8 +10,10 @@ namespace pw {
 // MI355X: 1..64 all land within 1.0-1.4 ms for 10 000 2 kb pairs -- the walk is bound by instructions per
 // step, not by latency -- so the default packs 64).
 __global__ __launch_bounds__(64) void k_trace(const TraceParams p, const int walkers) {
+  // each walker's window of the mask plane; the +1 keeps the lanes' windows on different LDS banks
+  __shared__ uint32_t win[64][WIN_WORDS + 1];
   const int pair = (int)blockIdx.x * walkers + (int)threadIdx.x;
-  if ((int)threadIdx.x < walkers && pair < p.npairs) trace_walk(p, pair);
+  if ((int)threadIdx.x < walkers && pair < p.npairs) trace_walk(p, pair, win[threadIdx.x]);
 }
 
 // K4b, wave-parallel: one wavefront per pair, 64 transcript positions per pass.  The (x, y) each

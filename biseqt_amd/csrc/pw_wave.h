@@ -780,7 +780,11 @@ PW_FN int pw_first_op(uint32_t mask) {   // index of the lowest set bit: 0 B, 1 
 // cache: no loads at all, just byte stores of the ops.  A lane that leaves its cached window idles
 // until the others do; all refill together.  Sequence letters are not read here: diagonal moves are
 // written as 'X' and turned into 'M'/'S' by the fix-up pass (K4b), which is fully parallel.
-PW_FN void trace_walk(const TraceParams& p, int pair) {
+// Window of the mask plane a walker keeps on chip: WIN_B consecutive blocks x 2 adjacent diagonal groups
+// (4 diagonals each), one dword per (block, group, diagonal): 64 steps along the path x 8 diagonals.
+enum { WIN_B = 4, WIN_WORDS = WIN_B * 2 * 4 };
+
+PW_FN void trace_walk(const TraceParams& p, int pair, uint32_t* win /* WIN_WORDS dwords private to this walker (LDS) */) {
   // everything the loops need is copied into locals first: the byte stores of the ops go through a
   // uint8_t*, which the compiler must assume aliases the descriptors
   const PairDesc pdv = p.pairs[pair];
@@ -799,33 +803,44 @@ PW_FN void trace_walk(const TraceParams& p, int pair) {
   uint8_t* __restrict__ tx = p.transcripts + pdv.tx_off;
   const int lgG = bk < 4 ? 1 : 2;               // log2 of the dwords per lane group (pw_types.h: mask_word_index)
   const int G = 1 << lgG;
-  const int njg = bk >> lgG;
+  const int njg = bk >> lgG;                    // groups per lane
+  const int ngroups = (ndiag + G - 1) >> lgG;   // groups that hold in-band diagonals
   int pos = pdv.tx_cap;           // ops are written backwards, ending right-aligned in the slot
   int nms = 0, bad = 0;
   int prev = 3;                   // op that led to the current cell; "M" makes the end cell use its first choice (pw.c:123)
   bool done = false;
   while (!done) {
-    // ---- refill: groups of block cb and cb - 1 around the current cell ----
+    // ---- refill: blocks cb .. cb - 3 of the current cell's diagonal group and of the neighbouring group on
+    //      the side the cell sits on (paths drift by single diagonals); all loads issued back to back ----
     const int dd0 = x - y - dmin, t0 = x + y - s0;
     if (x < 0 || y < 0 || dd0 < 0 || dd0 >= ndiag) { bad = 1; break; }   // never expected: see below
-    const int cln = dd0 / bk, cjg = (dd0 - cln * bk) >> lgG, cb = t0 >> 4;
-    // two unconditional 16-byte loads issued back to back (for bk = 2 a group is 8 bytes and the upper half
-    // of the load is the neighbouring lane's group: in bounds thanks to the slack behind the mask workspace)
-    const int cbm = cb > 0 ? cb - 1 : 0;
-    const U4 c0 = *(const U4*)(plane + ((uint64_t)((uint64_t)cb * njg + cjg) * nl + cln) * G);
-    const U4 c1 = *(const U4*)(plane + ((uint64_t)((uint64_t)cbm * njg + cjg) * nl + cln) * G);
-    // ---- step while the cell is inside the cached window ----
+    const int cb = t0 >> 4;
+    const int ga = dd0 >> lgG;
+    int gb = ((dd0 & (G - 1)) >= (G >> 1)) ? ga + 1 : ga - 1;
+    gb = gb < 0 ? ga + 1 : (gb >= ngroups ? ga - 1 : gb);
+    if (gb < 0) gb = ga;          // a band of a single group
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+      const int gg = s2 ? gb : ga;
+      const int ln = gg / njg, jg = gg - ln * njg;
+#pragma unroll
+      for (int k = 0; k < WIN_B; k++) {
+        const int bb = cb - k > 0 ? cb - k : 0;
+        // (for bk = 2 a group is 8 bytes: the upper half of the 16-byte load is the neighbouring lane's group,
+        //  in bounds thanks to the slack behind the mask workspace, and never selected below)
+        const U4 v = *(const U4*)(plane + ((uint64_t)((uint64_t)bb * njg + jg) * nl + ln) * G);
+        uint32_t* wslot = win + (k * 2 + s2) * 4;
+        wslot[0] = v.x; wslot[1] = v.y; wslot[2] = v.z; wslot[3] = v.w;
+      }
+    }
+    // ---- step while the cell is inside the window: no global loads, only byte stores of the ops ----
     while (true) {
       const int dd = x - y - dmin, t = x + y - s0;
       // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
       if (x < 0 || y < 0 || dd < 0 || dd >= ndiag) { bad = 1; done = true; break; }
-      // inside the cached window?  (bk need not be a power of two: compare against the window's diagonal range)
-      const int j = dd - cln * bk, jg = j >> lgG, b = t >> 4;
-      if (j < 0 || j >= bk || jg != cjg || (b != cb && b != cb - 1)) break;   // miss: refill
-      const int q = j & (G - 1);
-      const uint32_t wx = (b == cb) ? c0.x : c1.x, wy = (b == cb) ? c0.y : c1.y;
-      const uint32_t wz = (b == cb) ? c0.z : c1.z, ww = (b == cb) ? c0.w : c1.w;
-      const uint32_t w = q == 0 ? wx : q == 1 ? wy : q == 2 ? wz : ww;
+      const int gg = dd >> lgG, b = t >> 4, kb = cb - b;
+      if ((gg != ga && gg != gb) || kb < 0 || kb >= WIN_B) break;              // miss: refill
+      const uint32_t w = win[(kb * 2 + (gg == ga ? 0 : 1)) * 4 + (dd & (G - 1))];
       const uint32_t pm = (w >> (4 * (7 - ((t & 15) >> 1)))) & 15u;
       // which kept choice of this cell is the base of the step that led here
       int op;

@@ -188,7 +188,8 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   tp.pairs = &pd; tp.arena = arena.data(); tp.masks = masks.data(); tp.results = &res;
   tp.transcripts = tx.data(); tp.npairs = 1;
   tp.gosign = go < 0 ? -1 : (go > 0 ? 1 : 0); tp.banded = a.banded; tp.ends = nullptr;
-  pw::trace_walk(tp, 0);
+  uint32_t win[pw::WIN_WORDS];
+  pw::trace_walk(tp, 0, win);
   pw::trace_fixup_serial(tp, 0);
   info[4] = res.opt_i; info[5] = res.opt_j; info[6] = res.origin_idx; info[7] = res.mutant_idx;
   info[8] = res.tx_len; info[9] = res.status;
