@@ -72,6 +72,15 @@ PW_DECL(f64, double)
 PW_DECL16(4) PW_DECL16(8) PW_DECL16(12) PW_DECL16(16) PW_DECL16(20) PW_DECL16(24) PW_DECL16(28) PW_DECL16(32)
 #undef PW_DECL16
 
+hipError_t launch_fill_mw_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
+hipError_t launch_fill_mw_f64(const FillParams<double>&, int, int, int, hipStream_t);
+hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st) {
+  return launch_fill_mw_i32(a, variant, nw, nblocks, st);
+}
+hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int nw, int nblocks, hipStream_t st) {
+  return launch_fill_mw_f64(a, variant, nw, nblocks, st);
+}
+
 hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st) {
   switch (bk) {
     case 4: return launch_fill16_bk4(a, seg, nwaves, st);

@@ -20,7 +20,8 @@
 //   * every 16 steps each slot has accumulated 8 tie masks = one dword; the wave stores them with
 //     16-byte-per-lane, 1 KiB-contiguous stores (layout: pw_types.h, mask_word_index).
 //
-// The file is written against a tiny platform policy P (lane id, wave shifts, shuffles, barrier) so
+// The file is written against a tiny platform policy P (lane id and count, shifts by one lane, shuffles,
+// broadcast across the wavefronts of a workgroup) so
 // that the very same lane program is compiled by hipcc into the gfx950 kernels (pw_kernels.hip) and
 // by g++ into a 64-fiber lockstep emulator used only by the CPU tests (tests/emu).  PW_FN is the
 // function qualifier each side supplies.
@@ -75,6 +76,18 @@ template <class P> PW_FN double xshfl_xor(double v, int m) {
 template <class P> PW_FN uint64_t xshfl_xor(uint64_t v, int m) {
   uint32_t lo = (uint32_t)P::shfl_xor((int32_t)(uint32_t)v, m);
   uint32_t hi = (uint32_t)P::shfl_xor((int32_t)(uint32_t)(v >> 32), m);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <class P> PW_FN int32_t xwave_bcast(int32_t v, int w) { return P::wave_bcast(v, w); }
+template <class P> PW_FN double xwave_bcast(double v, int w) {
+  D2I a, r; a.d = v;
+  r.i[0] = P::wave_bcast(a.i[0], w); r.i[1] = P::wave_bcast(a.i[1], w);
+  return r.d;
+}
+template <class P> PW_FN uint64_t xwave_bcast(uint64_t v, int w) {
+  const uint32_t lo = (uint32_t)P::wave_bcast((int32_t)(uint32_t)v, w);
+  const uint32_t hi = (uint32_t)P::wave_bcast((int32_t)(uint32_t)(v >> 32), w);
   return ((uint64_t)hi << 32) | lo;
 }
 
@@ -313,7 +326,7 @@ struct WaveFill {
     const int f = (pd.s0 - pd.dmin) >> 1;       // y of diagonal dd = 0 on step t = 0
     xbase = e + lane * R;
     ybase = f - lane * R;
-    xfeed_o = e + 64 * R - 1;                   // letter o[xbase + R - 1] of a virtual lane 64
+    xfeed_o = e + P::nlanes() * R - 1;          // letter o[xbase + R - 1] of a virtual lane beyond the last one
     yfeed_m = f;                                // letter m[ybase] of lane 0
 #pragma unroll
     for (int j = 0; j < BK; j++) {
@@ -382,6 +395,18 @@ struct WaveFill {
       const int ox = P::shfl_xor(cx, off), oy = P::shfl_xor(cy, off), oh = P::shfl_xor(hv, off);
       const bool take = oh && (!hv || os > cs || (os == cs && ok_ < ck));
       if (take) { cs = os; ck = ok_; cx = ox; cy = oy; hv = 1; }
+    }
+    // several wavefronts per pair (wide bands): reduce the per-wave winners the same way
+    if (P::nwaves() > 1) {
+      T bs = cs; uint64_t bk_ = ck; int bx = cx, by = cy, bh = 0;
+      for (int wv = 0; wv < P::nwaves(); wv++) {
+        const T os = xwave_bcast<P>(cs, wv);
+        const uint64_t ok_ = xwave_bcast<P>(ck, wv);
+        const int ox = P::wave_bcast(cx, wv), oy = P::wave_bcast(cy, wv), oh = P::wave_bcast(hv, wv);
+        const bool take = oh && (!bh || os > bs || (os == bs && ok_ < bk_));
+        if (take) { bs = os; bk_ = ok_; bx = ox; by = oy; bh = 1; }
+      }
+      cs = bs; ck = bk_; cx = bx; cy = by; hv = bh;
     }
     if (lane == 0) {
       Result r;

@@ -40,6 +40,7 @@ int fail(const std::string& msg) { g_err = msg; return -1; }
 
 struct BkClass {
   int bk = 0;
+  int nw = 1;                   // wavefronts per pair (> 1: multi-wavefront kernel for wide bands)
   std::vector<int32_t> order;   // pair indices, largest table first
   int32_t* d_order = nullptr;
 };
@@ -187,16 +188,22 @@ int batch_build(pw_batch* b) {
   for (int32_t k = 0; k < b->n; k++) {
     pw::PairDesc& d = b->descs[k];
     if (!d.solvable) continue;
-    int bk, nl;
+    int bk, nl, nw = 1;
     if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
     else {
       bk = pw::plan_pick_bk(d.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
       nl = 64;
       if (bk == 0) {
-        char msg[160];
-        snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); tiled kernel not built yet",
-                 (int)k, d.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
-        return fail(msg);
+        // wider than one wavefront holds: a workgroup of nw wavefronts, 2048 diagonals each
+        bk = 32;
+        nw = (d.ndiag + 2047) / 2048;
+        nl = 64 * nw;
+        if (nw > pw::kMaxWavesPerPair) {
+          char msg[200];
+          snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); the tiled single-pair "
+                   "kernel is not built yet", (int)k, d.ndiag, 2048 * pw::kMaxWavesPerPair);
+          return fail(msg);
+        }
       }
     }
     d.bk = bk; d.nl = nl;
@@ -205,8 +212,8 @@ int batch_build(pw_batch* b) {
     d.h_off = h_elems;
     if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)d.ndiag * d.h_pitch;
     size_t ci = 0;
-    for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk) break;
-    if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; }
+    for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk && b->classes[ci].nw == nw) break;
+    if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; b->classes.back().nw = nw; }
     b->classes[ci].order.push_back(k);
   }
   for (auto& c : b->classes)
@@ -285,7 +292,8 @@ int launch_all_fills(pw_batch* b, hipStream_t st) {
   a.go = (T)b->go; a.ge = (T)b->ge;
   for (auto& c : b->classes) {
     a.order = c.d_order;
-    HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
+    if (c.nw > 1) HIP_TRY(pw::launch_fill_mw(a, b->variant, c.nw, (int)c.order.size(), st));
+    else HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
   }
   return 0;
 }
@@ -553,9 +561,9 @@ int dptable_init(dptable* T) {
       return -1;
     }
   }
-  if (pw::plan_pick_bk(pl.ndiag, pw::kSupportedBK, pw::kNumSupportedBK) == 0 && pl.ndiag > 0) {
+  if (pl.ndiag > 2048 * pw::kMaxWavesPerPair) {
     fprintf(stderr, "pwlib: %d diagonals exceed the widest GPU fill kernel (%d); refusing (no CPU fallback)\n",
-            pl.ndiag, 64 * pw::kSupportedBK[pw::kNumSupportedBK - 1]);
+            pl.ndiag, 2048 * pw::kMaxWavesPerPair);
     return -1;
   }
   T->num_rows = pl.num_rows;
@@ -619,7 +627,9 @@ intpair dptable_solve(dptable* T) {
   pr.origin_off = 0; pr.mutant_off = (uint64_t)moff; pr.origin_len = X; pr.mutant_len = Y;
   pr.dmin = prob->mode == BANDED_MODE ? prob->banded_params->dmin : 0;
   pr.dmax = prob->mode == BANDED_MODE ? prob->banded_params->dmax : 0;
-  const bool want_table = prob->mode == STD_MODE && !env_int("PWLIB_NO_TABLE", 0);
+  // the full table (host: 48 B per cell) is materialised for tables up to 2^24 cells; beyond that only the
+  // optimal cell is (table_scores-style callers need PWLIB_NO_TABLE unset and a table that size)
+  const bool want_table = prob->mode == STD_MODE && !env_int("PWLIB_NO_TABLE", 0) && h->ncells <= (1 << 24);
   if (h->batch) { pw_batch_destroy(h->batch); h->batch = nullptr; }
   h->batch = pw_batch_create(env_int("PWLIB_DEVICE", 0), &sc, 1, &pr, arena.size(), want_table ? PW_FLAG_DUMP_SCORES : 0);
   if (!h->batch) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); return none; }

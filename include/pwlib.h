@@ -121,7 +121,7 @@ typedef struct alignment {
 // prints the same messages to stdout, rejects infeasible banded-global problems), allocates
 // num_rows / row_lens / the host cell rows (all cells empty).  Returns 0, or -1 on error -- also for
 // problems this library does not support (max_new_mins > 0, letters >= 256, a band wider than the
-// widest kernel): it fails loudly on stderr, it never falls back to a CPU path.
+// widest kernel: 16384 diagonals): it fails loudly on stderr, it never falls back to a CPU path.
 int dptable_init(dptable* T);
 
 // dptable_free: releases everything dptable_init / dptable_solve / dptable_traceback allocated for T,

@@ -78,6 +78,9 @@ struct EmuP {
   static int32_t shl1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, old); }
   static int32_t shfl_xor(int32_t v, int m) { Emu* e = Emu::self; return e->exchange(v, e->cur ^ m, 0); }
   static int32_t uniform(int32_t v) { return v; }
+  static int nlanes() { return 64; }
+  static int nwaves() { return 1; }
+  static int32_t wave_bcast(int32_t v, int) { return v; }
 };
 
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>

@@ -90,7 +90,7 @@ def test_unsupported_problems_fail_loudly(capfd):
     lib = R.load(W.PWLIB_SO)
     P = R.Problem([0, 1, 2], [0, 1], L=4, max_new_mins=3)
     assert lib.dptable_init(C.byref(P.table)) == -1
-    P = R.Problem([0] * 3000, [0] * 3000, L=4)      # 6001 diagonals > widest kernel: refused, no CPU fallback
+    P = R.Problem([0] * 9000, [0] * 9000, L=4)      # 18001 diagonals > widest kernel: refused, no CPU fallback
     assert lib.dptable_init(C.byref(P.table)) == -1
     C.CDLL(None).fflush(None)
     err = capfd.readouterr().err

@@ -311,3 +311,59 @@ def test_traceback_from_explicit_end_cells(oracle):
         tx = b.transcripts(res)[0]
     r = oracle.solve(o[:30], m[:28], L=4, match=1, mismatch=-1, go=-1, ge=-1)   # global: prefix problem
     assert tx == r['transcript']
+
+
+def test_wide_bands_multi_wavefront(oracle):
+    """Bands wider than one wavefront holds (> 2048 diagonals): the multi-wavefront kernel (LDS halos between
+    the wavefronts of a workgroup), all score types / variants, through the batch API and through Aligner."""
+    from biseqt_amd import synth, _pwlib as W
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(31)
+    o = synth.rand_seqs(rng, 1, 1500)[0]
+    m = synth.mutate(rng, o, 0.08, 0.04, 0.4)
+    o2 = synth.rand_seqs(rng, 1, 2600)[0]
+    m2 = synth.mutate(rng, o2[300:2400], 0.05, 0.03, 0.3)
+    cases = [
+        (o, m, dict(mode=0, alntype=0), 0),                                   # STD GLOBAL, ~3000 diagonals
+        (o, m, dict(mode=0, alntype=1), 0),                                   # STD LOCAL
+        (o, m, dict(mode=0, alntype=4), W.PW_FLAG_FORCE_F64),                 # STD OVERLAP, f64
+        (o2, m2, dict(mode=1, alntype=2, diag_range=(-1900, 2500)), 0),       # B_OVERLAP, 4401 diagonals: 3 wavefronts
+        (o2, m2, dict(mode=1, alntype=1, diag_range=(-1900, 2500)), W.PW_FLAG_FORCE_GENERIC),
+    ]
+    for o_, m_, kw, flags in cases:
+        bkw = dict(alnmode=kw['mode'], alntype=kw['alntype'], alphabet_len=4, match_score=1, mismatch_score=-3,
+                   go_score=-5, ge_score=-2, flags=flags)
+        if 'diag_range' in kw:
+            bkw['diag_range'] = kw['diag_range']
+        with BatchAligner([(o_, m_), (m_, o_)] if kw['mode'] == 0 else [(o_, m_)], **bkw) as b:
+            assert 'k_fill' in b.kernel_name
+            res = b.run()
+            txs = b.transcripts(res)
+        r = oracle.solve(o_, m_, L=4, match=1, mismatch=-3, go=-5, ge=-2, **kw)
+        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'], kw
+        assert res['score'][0] == r['score'] and txs[0] == r['transcript'], kw
+        assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
+        if kw['mode'] == 0:
+            r2 = oracle.solve(m_, o_, L=4, match=1, mismatch=-3, go=-5, ge=-2, **kw)
+            assert res['score'][1] == r2['score'] and txs[1] == r2['transcript'], kw
+
+
+def test_aligner_standard_mode_two_kb(oracle):
+    """A 2 kb x 2 kb standard-mode problem through the drop-in ABI (4001 diagonals: two wavefronts)."""
+    from biseqt_amd import synth
+    from biseqt_amd.pw import Aligner, LOCAL
+    from biseqt_amd.sequence import Alphabet, Sequence
+    rng = synth.rng_for(8)
+    o = synth.rand_seqs(rng, 1, 2000)[0]
+    m = synth.mutate(rng, o, 0.1, 0.05, 0.3)
+    A = Alphabet('ACGT')
+    with Aligner(Sequence(A, o.tolist()), Sequence(A, m.tolist()), alntype=LOCAL, match_score=1,
+                 mismatch_score=-3, go_score=-5, ge_score=-2) as aligner:
+        score = aligner.solve()
+        aln = aligner.traceback()
+        table = aligner.table_scores()
+    r = oracle.solve(o, m, L=4, alntype=oracle.LOCAL, match=1, mismatch=-3, go=-5, ge=-2, want_table=True)
+    assert score == r['score'] and aln.transcript == r['transcript']
+    assert (aln.origin_start, aln.mutant_start) == (r['origin_idx'], r['mutant_idx'])
+    H = r['H'].reshape(len(o) + 1, len(m) + 1)
+    assert np.array_equal(np.array(table), H[:len(o), :len(m)])
