@@ -551,8 +551,9 @@ struct WaveFill16 {
     uint32_t Hn = pk::max(pk::max(up, left), hM);
     if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
     else Hn = pk::max(Hn, 0u);                                   // B: an alignment may begin anywhere, score 0
-    const uint32_t nD = pk::minu(pk::sub(Hn, up), ONE);
-    const uint32_t nI = pk::minu(pk::sub(Hn, left), ONE);
+    // "is the candidate kept" only asks whether H == candidate: xor (a 2-cycle op) instead of a packed subtract
+    const uint32_t nD = pk::minu(Hn ^ up, ONE);
+    const uint32_t nI = pk::minu(Hn ^ left, ONE);
     const uint32_t nB = pk::minu(Hn, ONE);
     const uint32_t hg = pk::add(Hn, geb);
     Us = pk::mad(nD, GOV, hg);                                   // (H + ge) + go unless a D choice is kept
@@ -561,8 +562,8 @@ struct WaveFill16 {
     acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
     const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV) : Hn;
     const uint32_t bn = pk::max(bests, Ht);
-    const uint32_t u = pk::minu(pk::sub(bn, bests), ONE);       // 1 where the best strictly improved
-    bts = pk::mad(u, pk::sub(tv, bts), bts);
+    const uint32_t u = pk::minu(bn ^ bests, ONE);               // 1 where the best strictly improved
+    bts = pk::mad(u, tv - bts, bts);                             // steps only grow: no borrow between the halves
     bests = bn;
     Hs = Hn;
   }

@@ -167,6 +167,7 @@ int batch_build(pw_batch* b) {
     // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
     // 64 x BK diagonal slots busy.  Packing is chosen when it buys at least 25 % more busy slots.
     const char* forced = getenv("PWLIB_PACKED_BK");        // tuning / A-B: "<bk>" or "<bk>s" (force packing)
+    if (forced && !*forced) forced = nullptr;
     const double meannd = (double)sumnd / nsolv;
     double util1 = -1, utilp = -1; int bk1 = 0, bkp = 0, nlp = 0;
     for (int i = 0; i < pw::kNumPackedBK; i++) {

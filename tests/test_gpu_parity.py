@@ -367,3 +367,28 @@ def test_aligner_standard_mode_two_kb(oracle):
     assert (aln.origin_start, aln.mutant_start) == (r['origin_idx'], r['mutant_idx'])
     H = r['H'].reshape(len(o) + 1, len(m) + 1)
     assert np.array_equal(np.array(table), H[:len(o), :len(m)])
+
+
+@pytest.mark.parametrize('radius,n', [(4, 37), (16, 50), (50, 23), (120, 11)])
+def test_lane_packed_batches(oracle, radius, n):
+    """Narrow bands: several pairs share a wavefront (lane packing), including a ragged last wavefront and
+    pairs of different lengths inside one wavefront (different block counts and steady ranges)."""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(100 + radius)
+    pairs = []
+    for k in range(n):
+        o = synth.rand_seqs(rng, 1, int(rng.integers(40, 700)))[0]
+        pairs.append((o, synth.mutate(rng, o, 0.06, 0.03, 0.3)))
+    for typ, mode, dr in ((1, 1, (-radius, radius)),):
+        with BatchAligner(pairs, alnmode=mode, alntype=typ, alphabet_len=4, diag_range=dr, check_band=False,
+                          match_score=2, mismatch_score=-3, go_score=-4, ge_score=-1) as b:
+            name = b.kernel_name
+            res = b.run()
+            txs = b.transcripts(res)
+        assert 'k_fill16' in name and 'true' in name, name       # the lane-packed form was chosen
+        for k, (o, m) in enumerate(pairs):
+            r = oracle.solve(o, m, L=4, mode=mode, alntype=typ, diag_range=dr, match=2, mismatch=-3, go=-4, ge=-1)
+            assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (radius, k)
+            assert res['score'][k] == r['score'] and txs[k] == r['transcript'], (radius, k)
+            assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
