@@ -33,6 +33,9 @@ struct DevP {
   PW_FN static int nlanes() { return 64; }
   PW_FN static int nwaves() { return 1; }
   PW_FN static int32_t wave_bcast(int32_t v, int) { return v; }
+  PW_FN static int lane0() { return 0; }
+  PW_FN static bool central() { return true; }
+  static constexpr bool kVirtualLanes = false;
 };
 
 // Platform policy for bands wider than one wavefront holds: a workgroup of blockDim.x / 64 wavefronts is one
@@ -41,6 +44,9 @@ struct DevP {
 // Every wavefront runs the same sequence of shifts, so the barriers are reached uniformly.
 struct DevPM {
   PW_FN static int lane() { return (int)threadIdx.x; }
+  PW_FN static int lane0() { return 0; }
+  PW_FN static bool central() { return true; }
+  static constexpr bool kVirtualLanes = false;
   PW_FN static int nlanes() { return (int)blockDim.x; }
   PW_FN static int nwaves() { return (int)(blockDim.x >> 6); }
   PW_FN static int32_t shr1(int32_t v, int32_t old) {

@@ -88,6 +88,12 @@ struct FillParams {
   const PairDesc* pairs;
   const int32_t* order;       // launch order (longest first) or null
   const WaveDesc* waves;      // lane-packed kernels: one descriptor per wavefront
+  // tiled single-pair kernel (K2b): per-diagonal state handed from one time block to the next, laid out as
+  // [5][st_pitch]: H, U, L, best, bestT (all as T); the launch covers blocks [tile_b0, tile_b0 + tile_nb)
+  const T* st_in;
+  T* st_out;
+  int32_t st_pitch;
+  int32_t tile_b0, tile_nb;
   const uint8_t* arena;
   uint32_t* masks;
   T* hdump;                   // score plane or null

@@ -237,7 +237,8 @@ struct WaveFill {
   template <bool RAMP>
   PW_FN void iteration(int it, int k) {
     // even step: slot 0 takes its "up" offer from the previous lane's last slot
-    const T uin = xshr1<P>(U[BK - 1], Tr::neg());
+    T uin = xshr1<P>(U[BK - 1], Tr::neg());
+    if (P::kVirtualLanes) uin = lane == 0 ? Tr::neg() : uin;    // nothing lies below diagonal 0 of the band
     EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
     // the origin window moves on by one letter: lane l takes lane l+1's lowest letter, the last lane
     // is fed from the arena
@@ -307,27 +308,27 @@ struct WaveFill {
   }
 
   PW_FN void store_masks(int b) {
-    if (lane * BK < ndiag) {
+    if (lane >= 0 && lane * BK < ndiag && P::central()) {
       uint32_t* dst = a.masks + pd.mask_off;
 #pragma unroll
       for (int j = 0; j < BK; j++) dst[mask_word_index(BK, pd.nl, b, lane, j)] = m[j];
     }
   }
 
-  PW_FN void init() {
+  PW_FN void init(int it0 = 0) {
     lane = P::lane();
     X = pd.X; Y = pd.Y; ndiag = pd.ndiag;
     oseq = a.arena + pd.o_off; mseq = a.arena + pd.m_off;
     olast = X > 0 ? X - 1 : 0; mlast = Y > 0 ? Y - 1 : 0;
     owlast = olast >> 2; mwlast = mlast >> 2;
-    njl = ndiag - lane * BK;
+    njl = lane < 0 ? 0 : ndiag - lane * BK;      // (tiles may carry virtual lanes below diagonal 0)
     // s0 == dmin (mod 2): e, f are exact
     const int e = (pd.s0 + pd.dmin) >> 1;       // x of diagonal dd = 0 on step t = 0
     const int f = (pd.s0 - pd.dmin) >> 1;       // y of diagonal dd = 0 on step t = 0
-    xbase = e + lane * R;
-    ybase = f - lane * R;
+    xbase = e + it0 + lane * R;
+    ybase = f + it0 - lane * R;
     xfeed_o = e + P::nlanes() * R - 1;          // letter o[xbase + R - 1] of a virtual lane beyond the last one
-    yfeed_m = f;                                // letter m[ybase] of lane 0
+    yfeed_m = f - P::lane0() * R;               // letter m[ybase] of the first lane
 #pragma unroll
     for (int j = 0; j < BK; j++) {
       H[j] = Tr::neg(); U[j] = Tr::neg(); L[j] = Tr::neg();
@@ -353,6 +354,44 @@ struct WaveFill {
       store_masks(b);
     }
     finish();
+  }
+
+  // ---- K2b: one tile of a time-blocked, ghost-zone tiled fill (tables too wide for one workgroup) -------
+  // The workgroup owns P::nlanes() - P::lane0() lanes of the band; the outer `ghost` lanes on each side are
+  // recomputed copies of the neighbouring tiles' lanes.  Dependencies travel one diagonal per step, so after
+  // tile_nb * 16 <= ghost * BK steps the centre lanes (P::central()) are still exact; only they store masks
+  // and hand their state to the next time block.  State: [5][st_pitch] = H, U, L, best, bestT per diagonal.
+  PW_FN void run_tile() {
+    const int b0 = a.tile_b0;
+    init(8 * b0);
+    const int pitch = a.st_pitch;
+    if (b0 > 0) {
+#pragma unroll
+      for (int j = 0; j < BK; j++) {
+        const int dd = lane * BK + j;
+        if (lane >= 0 && dd < ndiag) {
+          H[j] = a.st_in[dd]; U[j] = a.st_in[pitch + dd]; L[j] = a.st_in[2 * pitch + dd] + blkL[j];
+          best[j] = a.st_in[3 * pitch + dd]; bestT[j] = (int32_t)a.st_in[4 * pitch + dd];
+        }
+      }
+    }
+    feed_issue(b0);
+    for (int b = b0; b < b0 + a.tile_nb; b++) {
+      feed_commit(b);
+      if (b + 1 < b0 + a.tile_nb) feed_issue(b + 1);
+      block<true>(b);          // the predicated body everywhere (first version: exact, not yet tuned)
+      store_masks(b);
+    }
+    if (P::central()) {
+#pragma unroll
+      for (int j = 0; j < BK; j++) {
+        const int dd = lane * BK + j;
+        if (lane >= 0 && dd < ndiag) {
+          a.st_out[dd] = H[j]; a.st_out[pitch + dd] = U[j]; a.st_out[2 * pitch + dd] = L[j];
+          a.st_out[3 * pitch + dd] = best[j]; a.st_out[4 * pitch + dd] = (T)bestT[j];
+        }
+      }
+    }
   }
 
   // ---- end-cell search: reduce (score desc, scan rank asc) over the in-band diagonals ----------

@@ -81,6 +81,9 @@ struct EmuP {
   static int nlanes() { return 64; }
   static int nwaves() { return 1; }
   static int32_t wave_bcast(int32_t v, int) { return v; }
+  static int lane0() { return 0; }
+  static bool central() { return true; }
+  static constexpr bool kVirtualLanes = false;
 };
 
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
