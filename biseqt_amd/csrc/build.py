@@ -41,6 +41,10 @@ def _jobs():
         obj = os.path.join(OBJ_DIR, 'pw_fill_mw_%s.o' % tn)
         cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_mw_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_mw_tu.hip')]))
+    for tn, t in TYPES:
+        obj = os.path.join(OBJ_DIR, 'pw_fill_tile_%s.o' % tn)
+        cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_tile_tu.hip'), '-o', obj]
+        jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tile_tu.hip')]))
     for bk in PACKED_BKS:
         obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d.o' % bk)
         # max-ilp scheduling: dependent VOP3P ops need a wait state between them; the default (occupancy first)

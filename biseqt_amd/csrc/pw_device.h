@@ -113,6 +113,129 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int
   w.run();
 }
 
+// Platform policy of a TILE of the time-blocked single-pair kernel (K2b): a workgroup of kTileLanes lanes whose
+// lane indices are global (tile * kTileCentral - kTileGhost + thread); the first kTileGhost and the last
+// kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.
+constexpr int kTileLanes = 256, kTileGhost = 32, kTileCentral = kTileLanes - 2 * kTileGhost;
+struct DevPT {
+  PW_FN static int lane0() { return (int)blockIdx.x * kTileCentral - kTileGhost; }
+  PW_FN static int lane() { return lane0() + (int)threadIdx.x; }
+  PW_FN static int nlanes() { return lane0() + kTileLanes; }      // global index one past this tile's last lane
+  PW_FN static int nwaves() { return kTileLanes / 64; }
+  PW_FN static bool central() { return (int)threadIdx.x >= kTileGhost && (int)threadIdx.x < kTileLanes - kTileGhost; }
+  static constexpr bool kVirtualLanes = true;
+  PW_FN static int32_t shr1(int32_t v, int32_t old) {
+    __shared__ int32_t edge[kTileLanes / 64];
+    const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
+    int32_t r = __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if (l == 63) edge[w] = v;
+    __syncthreads();
+    if (l == 0 && w > 0) r = edge[w - 1];
+    __syncthreads();
+    return r;
+  }
+  PW_FN static int32_t shl1(int32_t v, int32_t old) {
+    __shared__ int32_t edge[kTileLanes / 64];
+    const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
+    int32_t r = __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    if (l == 0) edge[w] = v;
+    __syncthreads();
+    if (l == 63 && w + 1 < kTileLanes / 64) r = edge[w + 1];
+    __syncthreads();
+    return r;
+  }
+  PW_FN static int32_t shfl_xor(int32_t v, int m) { return __shfl_xor(v, m, 64); }
+  PW_FN static int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+  PW_FN static int32_t wave_bcast(int32_t v, int) { return v; }     // (the tile kernel has no in-kernel end search)
+};
+
+constexpr int kTileBK = 4;     // diagonals per lane of the tiled kernel: 768 centre diagonals, 128 ghost steps per launch
+static_assert(kTileBK == kTileBKHost && kTileCentral == kTileCentralLanes && kTileBlocks * 16 <= kTileGhost * kTileBK,
+              "tile geometry: host and device must agree, and a time block must fit the ghost zone");
+
+// K2b: one launch = one time block (tile_nb <= kTileGhost * kTileBK / 16 blocks) of ONE pair; grid = tiles.
+template <typename T, bool BANY, bool TRACK, bool GENERIC>
+__global__ __launch_bounds__(kTileLanes) void k_fill_tile(const FillParams<T> a, const int pair) {
+  __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
+  const T* tab = a.subst;
+  if (GENERIC) {
+    if (a.L <= kMaxLdsL) {
+      for (int i = (int)threadIdx.x; i < a.L * a.L; i += (int)blockDim.x) sub_lds[i] = a.subst[i];
+      __syncthreads();
+      tab = sub_lds;
+    }
+  }
+  const PairDesc pd = a.pairs[pair];
+  WaveFill<DevPT, T, kTileBK, BANY, TRACK, GENERIC> w(a, pd, tab);
+  w.pair_slot = pair;
+  w.run_tile();
+}
+
+// End-cell search of a tiled pair from the final per-diagonal state (same rules as WaveFill::finish).
+template <typename T>
+__global__ __launch_bounds__(256) void k_tile_finish(const FillParams<T> a, const int pair) {
+  using Tr = ScoreTraits<T>;
+  __shared__ T s_s[256]; __shared__ unsigned long long s_k[256]; __shared__ int s_x[256], s_y[256], s_h[256];
+  const PairDesc pd = a.pairs[pair];
+  const int X = pd.X, Y = pd.Y, endrule = a.endrule, pitch = a.st_pitch;
+  T cs = Tr::neg(); unsigned long long ck = ~0ull; int cx = -1, cy = -1, have = 0;
+  for (int dd = (int)threadIdx.x; dd < pd.ndiag; dd += 256) {
+    const int d = pd.dmin + dd;
+    const bool ends_right = d < X - Y;
+    const int lx = ends_right ? d + Y : X, ly = ends_right ? Y : X - d;
+    T s; unsigned long long k; int x, y; bool ok = true;
+    if (endrule == END_CORNER) { ok = d == X - Y; s = a.st_in[dd]; k = 0; x = X; y = Y; }
+    else if (endrule == END_STD_OVERLAP) { s = a.st_in[dd]; x = lx; y = ly; k = ends_right ? (unsigned)lx : (unsigned)(X + ly); }
+    else if (endrule == END_BANDED_OVERLAP) { s = a.st_in[dd]; x = lx; y = ly; k = (unsigned)dd; }
+    else {
+      const int tfirst = (d < 0 ? -d : d) - pd.s0;
+      const int aa = ((int)a.st_in[4 * pitch + dd] - tfirst) >> 1;
+      s = a.st_in[3 * pitch + dd]; x = aa + (d > 0 ? d : 0); y = aa - (d < 0 ? d : 0);
+      if (endrule == END_STD_LOCAL) k = (unsigned long long)(unsigned)x * (unsigned long long)(unsigned)(Y + 1) + (unsigned)y;
+      else k = ((unsigned long long)(unsigned)dd << 32) | (unsigned)aa;
+    }
+    if (ok && (!have || s > cs || (s == cs && k < ck))) { cs = s; ck = k; cx = x; cy = y; have = 1; }
+  }
+  s_s[threadIdx.x] = cs; s_k[threadIdx.x] = ck; s_x[threadIdx.x] = cx; s_y[threadIdx.x] = cy; s_h[threadIdx.x] = have;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const int o = (int)threadIdx.x + off;
+      if (s_h[o] && (!s_h[threadIdx.x] || s_s[o] > s_s[threadIdx.x] || (s_s[o] == s_s[threadIdx.x] && s_k[o] < s_k[threadIdx.x]))) {
+        s_s[threadIdx.x] = s_s[o]; s_k[threadIdx.x] = s_k[o]; s_x[threadIdx.x] = s_x[o]; s_y[threadIdx.x] = s_y[o]; s_h[threadIdx.x] = 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Result r;
+    r.score = (double)s_s[0];
+    r.opt_i = a.banded ? s_x[0] - s_y[0] - pd.dmin : s_x[0];
+    r.opt_j = a.banded ? (s_x[0] < s_y[0] ? s_x[0] : s_y[0]) : s_y[0];
+    r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;
+    if (!s_h[0] || (endrule == END_STD_LOCAL && !(s_s[0] > T(0)))) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; }
+    a.results[pair] = r;
+  }
+}
+
+template <typename T>
+hipError_t launch_tile_T(const FillParams<T>& a, int variant, int pair, int ntiles, hipStream_t st) {
+  const dim3 grid((unsigned)ntiles), block(kTileLanes);
+  switch (variant) {
+    case VAR_FAST_ANY_TRACK: hipLaunchKernelGGL((k_fill_tile<T, true, true, false>), grid, block, 0, st, a, pair); break;
+    case VAR_FAST_TRACK: hipLaunchKernelGGL((k_fill_tile<T, false, true, false>), grid, block, 0, st, a, pair); break;
+    case VAR_FAST: hipLaunchKernelGGL((k_fill_tile<T, false, false, false>), grid, block, 0, st, a, pair); break;
+    case VAR_GENERIC: hipLaunchKernelGGL((k_fill_tile<T, false, true, true>), grid, block, 0, st, a, pair); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_tile_finish_T(const FillParams<T>& a, int pair, hipStream_t st) {
+  hipLaunchKernelGGL((k_tile_finish<T>), dim3(1), dim3(256), 0, st, a, pair);
+  return hipGetLastError();
+}
+
 // K2a: one WORKGROUP (up to 8 wavefronts, 2048 diagonals each) per pair for bands wider than 2048 diagonals.
 template <typename T, bool BANY, bool TRACK, bool GENERIC>
 __global__ __launch_bounds__(512) void k_fill_mw(const FillParams<T> a) {

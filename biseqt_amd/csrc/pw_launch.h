@@ -29,6 +29,12 @@ hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwav
 static const int kMaxWavesPerPair = 8;
 hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st);
 hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int nw, int nblocks, hipStream_t st);
+// tiled single-pair kernel (K2b): tiles of kTileCentralDiags diagonals + ghosts, time blocks of kTileBlocks blocks
+static const int kTileBKHost = 4, kTileCentralLanes = 192, kTileBlocks = 8;   // must match pw_device.h (checked there)
+hipError_t launch_tile(const FillParams<int32_t>& a, int variant, int pair, int ntiles, hipStream_t st);
+hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int ntiles, hipStream_t st);
+hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st);
+hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
 
 }  // namespace pw

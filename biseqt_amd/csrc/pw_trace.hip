@@ -72,6 +72,15 @@ PW_DECL(f64, double)
 PW_DECL16(4) PW_DECL16(8) PW_DECL16(12) PW_DECL16(16) PW_DECL16(20) PW_DECL16(24) PW_DECL16(28) PW_DECL16(32)
 #undef PW_DECL16
 
+hipError_t launch_tile_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
+hipError_t launch_tile_f64(const FillParams<double>&, int, int, int, hipStream_t);
+hipError_t launch_tile_finish_i32(const FillParams<int32_t>&, int, hipStream_t);
+hipError_t launch_tile_finish_f64(const FillParams<double>&, int, hipStream_t);
+hipError_t launch_tile(const FillParams<int32_t>& a, int variant, int pair, int ntiles, hipStream_t st) { return launch_tile_i32(a, variant, pair, ntiles, st); }
+hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int ntiles, hipStream_t st) { return launch_tile_f64(a, variant, pair, ntiles, st); }
+hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st) { return launch_tile_finish_i32(a, pair, st); }
+hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st) { return launch_tile_finish_f64(a, pair, st); }
+
 hipError_t launch_fill_mw_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
 hipError_t launch_fill_mw_f64(const FillParams<double>&, int, int, int, hipStream_t);
 hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st) {

@@ -370,7 +370,7 @@ struct WaveFill {
       for (int j = 0; j < BK; j++) {
         const int dd = lane * BK + j;
         if (lane >= 0 && dd < ndiag) {
-          H[j] = a.st_in[dd]; U[j] = a.st_in[pitch + dd]; L[j] = a.st_in[2 * pitch + dd] + blkL[j];
+          H[j] = a.st_in[dd]; U[j] = a.st_in[pitch + dd]; L[j] = a.st_in[2 * pitch + dd];
           best[j] = a.st_in[3 * pitch + dd]; bestT[j] = (int32_t)a.st_in[4 * pitch + dd];
         }
       }

@@ -61,6 +61,9 @@ struct pw_batch {
   std::vector<pw::PairDesc> descs;
   std::vector<BkClass> classes;
   std::vector<pw::WaveDesc> waves;      // lane-packed kernel: one per wavefront
+  std::vector<int32_t> tiled;           // pairs that go through the time-blocked tiled kernel (K2b)
+  void* d_state[2] = {nullptr, nullptr}; // their per-diagonal state, double buffered (shared: pairs run one after another)
+  int32_t st_pitch = 0;
   int packed_seg = 0;
   pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
@@ -92,6 +95,8 @@ int batch_free_device(pw_batch* b) {
   if (b->d_subst) (void)hipFree(b->d_subst);
   if (b->d_ends) (void)hipFree(b->d_ends);
   if (b->d_waves) (void)hipFree(b->d_waves);
+  if (b->d_state[0]) (void)hipFree(b->d_state[0]);
+  if (b->d_state[1]) (void)hipFree(b->d_state[1]);
   if (b->ev_fill0) (void)hipEventDestroy(b->ev_fill0);
   if (b->ev_fill1) (void)hipEventDestroy(b->ev_fill1);
   if (b->ev_tr0) (void)hipEventDestroy(b->ev_tr0);
@@ -161,7 +166,8 @@ int batch_build(pw_batch* b) {
   else b->variant = pw::VAR_FAST;
   // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16
   int pbk = 0, pnl = 0, pseg = 0;
-  if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 && !(b->flags & PW_FLAG_NO_PACKED16) &&
+  if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 &&
+      !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED)) && maxnd <= 2048 &&
       nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 16000 && maxspan < 32000 && b->ge <= 0) {
     // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
     // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
@@ -190,8 +196,15 @@ int batch_build(pw_batch* b) {
     pw::PairDesc& d = b->descs[k];
     if (!d.solvable) continue;
     int bk, nl, nw = 1;
+    bool tiled = false;
     if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
-    else {
+    else if ((b->flags & PW_FLAG_FORCE_TILED) || d.ndiag > 2048 * pw::kMaxWavesPerPair) {
+      // wider than a workgroup holds (or forced): time-blocked tiles of the band, one pair after another
+      if (b->flags & PW_FLAG_DUMP_SCORES) return fail("the score plane is not available for tiled (very wide) tables");
+      bk = pw::kTileBKHost;
+      nl = (d.ndiag + bk - 1) / bk;
+      tiled = true;
+    } else {
       bk = pw::plan_pick_bk(d.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
       nl = 64;
       if (bk == 0) {
@@ -199,12 +212,6 @@ int batch_build(pw_batch* b) {
         bk = 32;
         nw = (d.ndiag + 2047) / 2048;
         nl = 64 * nw;
-        if (nw > pw::kMaxWavesPerPair) {
-          char msg[200];
-          snprintf(msg, sizeof msg, "pair %d: %d diagonals exceed the widest fill kernel (%d); the tiled single-pair "
-                   "kernel is not built yet", (int)k, d.ndiag, 2048 * pw::kMaxWavesPerPair);
-          return fail(msg);
-        }
       }
     }
     d.bk = bk; d.nl = nl;
@@ -212,6 +219,7 @@ int batch_build(pw_batch* b) {
     mask_words += (uint64_t)(d.nblocks + 1) * nl * bk;   // + one spare row: the branch-free stores of idle lanes land there
     d.h_off = h_elems;
     if (b->flags & PW_FLAG_DUMP_SCORES) h_elems += (uint64_t)d.ndiag * d.h_pitch;
+    if (tiled) { b->tiled.push_back(k); b->st_pitch = std::max(b->st_pitch, (d.ndiag + 63) / 64 * 64); continue; }
     size_t ci = 0;
     for (; ci < b->classes.size(); ci++) if (b->classes[ci].bk == bk && b->classes[ci].nw == nw) break;
     if (ci == b->classes.size()) { b->classes.emplace_back(); b->classes.back().bk = bk; b->classes.back().nw = nw; }
@@ -261,6 +269,10 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipMemcpy(b->d_subst, si.data(), 4 * si.size(), hipMemcpyHostToDevice));
   }
   if (b->n) HIP_TRY(hipMemcpy(b->d_pairs, b->descs.data(), sizeof(pw::PairDesc) * b->n, hipMemcpyHostToDevice));
+  if (!b->tiled.empty()) {
+    HIP_TRY(hipMalloc(&b->d_state[0], (size_t)5 * b->st_pitch * 8));
+    HIP_TRY(hipMalloc(&b->d_state[1], (size_t)5 * b->st_pitch * 8));
+  }
   if (!b->waves.empty()) {
     HIP_TRY(hipMalloc((void**)&b->d_waves, sizeof(pw::WaveDesc) * b->waves.size()));
     HIP_TRY(hipMemcpy(b->d_waves, b->waves.data(), sizeof(pw::WaveDesc) * b->waves.size(), hipMemcpyHostToDevice));
@@ -295,6 +307,22 @@ int launch_all_fills(pw_batch* b, hipStream_t st) {
     a.order = c.d_order;
     if (c.nw > 1) HIP_TRY(pw::launch_fill_mw(a, b->variant, c.nw, (int)c.order.size(), st));
     else HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
+  }
+  // K2b: tiled pairs, one after another; per pair one launch per time block, then the end-cell search
+  a.order = nullptr;
+  a.st_pitch = b->st_pitch;
+  for (int32_t k : b->tiled) {
+    const pw::PairDesc& d = b->descs[k];
+    const int ntiles = (d.nl + pw::kTileCentralLanes - 1) / pw::kTileCentralLanes;
+    int cur = 0;
+    for (int tb = 0; tb < d.nblocks; tb += pw::kTileBlocks) {
+      a.tile_b0 = tb; a.tile_nb = std::min(pw::kTileBlocks, d.nblocks - tb);
+      a.st_in = (const T*)b->d_state[cur]; a.st_out = (T*)b->d_state[cur ^ 1];
+      HIP_TRY(pw::launch_tile(a, b->variant, (int)k, ntiles, st));
+      cur ^= 1;
+    }
+    a.st_in = (const T*)b->d_state[cur];
+    HIP_TRY(pw::launch_tile_finish(a, (int)k, st));
   }
   return 0;
 }
@@ -365,6 +393,7 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   static thread_local char name[96];
   int bk = 0; size_t most = 0;
   for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; }
+  if (b->classes.empty() && !b->tiled.empty()) { snprintf(name, sizeof name, "k_fill_tile<%s> x time blocks", b->use_f64 ? "double" : "int"); return name; }
   const char* t = b->use_f64 ? "double" : "int";
   switch (b->variant) {
     case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false"); break;
@@ -509,7 +538,9 @@ const uint64_t kMagic = 0x70776c69622d6869ull;   // "pwlib-hi"
 struct Hidden {
   uint64_t magic;
   pw_batch* batch;
-  dpcell* cell_slab;          // all rows, back to back
+  dpcell* cell_slab;          // all rows, back to back (NULL for huge tables: lazy)
+  dpcell* opt_row;            // lazy tables: the one row that holds the optimal cell
+  bool lazy;
   alnchoice* choice_slab;     // materialised choices
   int64_t ncells;
   int L;
@@ -562,9 +593,9 @@ int dptable_init(dptable* T) {
       return -1;
     }
   }
-  if (pl.ndiag > 2048 * pw::kMaxWavesPerPair) {
+  if (pl.ndiag > (1 << 21)) {
     fprintf(stderr, "pwlib: %d diagonals exceed the widest GPU fill kernel (%d); refusing (no CPU fallback)\n",
-            pl.ndiag, 2048 * pw::kMaxWavesPerPair);
+            pl.ndiag, 1 << 21);
     return -1;
   }
   T->num_rows = pl.num_rows;
@@ -575,14 +606,18 @@ int dptable_init(dptable* T) {
   h->magic = kMagic; h->batch = nullptr; h->choice_slab = nullptr; h->L = 0; h->dmin_c = pl.dmin;
   h->alns = new std::vector<alignment*>();
   h->ncells = pl.cells;
-  h->cell_slab = (dpcell*)calloc((size_t)std::max<int64_t>(pl.cells, 1), sizeof(dpcell));   // all empty (:64-74)
-  if (!h->cell_slab) { fprintf(stderr, "pwlib: out of memory\n"); delete h->alns; free(T->row_lens); free(blk); return -1; }
+  // Tables beyond 2^26 cells (1 GiB of dpcell) do not get their cells on the host: the row-pointer array is
+  // there, rows are NULL, and dptable_solve allocates only the row of the optimal cell (what pw.py:272 reads).
+  h->lazy = pl.cells > ((int64_t)1 << 26);
+  h->opt_row = nullptr;
+  h->cell_slab = h->lazy ? nullptr : (dpcell*)calloc((size_t)std::max<int64_t>(pl.cells, 1), sizeof(dpcell));   // all empty (:64-74)
+  if (!h->lazy && !h->cell_slab) { fprintf(stderr, "pwlib: out of memory\n"); delete h->alns; free(T->row_lens); free(blk); return -1; }
   T->cells = (dpcell**)(blk + sizeof(Hidden));
   int64_t off = 0;
   for (int i = 0; i < pl.num_rows; i++) {
     const int len = prob->mode == STD_MODE ? Y + 1 : pw::plan_len(X, Y, pl.dmin + i);
     T->row_lens[i] = len;
-    T->cells[i] = h->cell_slab + off;
+    T->cells[i] = h->lazy ? nullptr : h->cell_slab + off;
     off += len;
   }
   return 0;
@@ -596,6 +631,7 @@ void dptable_free(dptable* T) {
   delete h->alns;
   free(h->choice_slab);
   free(h->cell_slab);
+  free(h->opt_row);
   h->magic = 0;
   free((char*)T->cells - sizeof(Hidden));
   free(T->row_lens);
@@ -657,6 +693,12 @@ intpair dptable_solve(dptable* T) {
       h->cell_slab[c].num_choices = 1; h->cell_slab[c].choices = ch;
     }
   } else if (res.opt_i >= 0 && res.opt_j >= 0) {
+    if (h->lazy) {
+      free(h->opt_row);
+      h->opt_row = (dpcell*)calloc((size_t)T->row_lens[res.opt_i], sizeof(dpcell));
+      if (!h->opt_row) { fprintf(stderr, "pwlib: out of memory\n"); return none; }
+      T->cells[res.opt_i] = h->opt_row;
+    }
     h->choice_slab = (alnchoice*)calloc(1, sizeof(alnchoice));
     if (!h->choice_slab) { fprintf(stderr, "pwlib: out of memory\n"); return none; }
     h->choice_slab->score = res.score; h->choice_slab->base = NULL; h->choice_slab->mins_cd = prob->max_new_mins;
@@ -696,7 +738,7 @@ alignment* dptable_traceback(dptable* T, intpair end) {
   // score of the END cell given (pw.c:148): the solve score for the optimal cell, the materialised
   // table for any other cell (standard mode), otherwise unknown
   if (end.i == res.opt_i && end.j == res.opt_j) a->score = res.score;
-  else if (T->cells[end.i][end.j].num_choices > 0) a->score = T->cells[end.i][end.j].choices[0].score;
+  else if (T->cells[end.i] && T->cells[end.i][end.j].num_choices > 0) a->score = T->cells[end.i][end.j].choices[0].score;
   else a->score = NAN;
   h->alns->push_back(a);
   return a;

@@ -90,8 +90,18 @@ def test_unsupported_problems_fail_loudly(capfd):
     lib = R.load(W.PWLIB_SO)
     P = R.Problem([0, 1, 2], [0, 1], L=4, max_new_mins=3)
     assert lib.dptable_init(C.byref(P.table)) == -1
-    P = R.Problem([0] * 9000, [0] * 9000, L=4)      # 18001 diagonals > widest kernel: refused, no CPU fallback
+    # a table wider than the widest kernel (2^21 diagonals) is refused, not handed to a CPU path
+    P = R.Problem([0], [0], L=4)
+    P.frame.origin_range.j = 1 << 21       # only the frame lengths are read by dptable_init
+    P.frame.mutant_range.j = 1 << 20
     assert lib.dptable_init(C.byref(P.table)) == -1
+    # a large standard-mode table is accepted without allocating its cells on the host (lazy rows)
+    P = R.Problem([0], [0], L=4)
+    P.frame.origin_range.j = 100000
+    P.frame.mutant_range.j = 100000
+    assert lib.dptable_init(C.byref(P.table)) == 0
+    assert P.table.num_rows == 100001 and P.table.row_lens[5] == 100001 and not P.table.cells[5]
+    lib.dptable_free(C.byref(P.table))
     C.CDLL(None).fflush(None)
     err = capfd.readouterr().err
     assert 'max_new_mins' in err and 'no CPU fallback' in err

@@ -393,3 +393,47 @@ def test_lane_packed_batches(oracle, radius, n):
             assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (radius, k)
             assert res['score'][k] == r['score'] and txs[k] == r['transcript'], (radius, k)
             assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def test_tiled_kernel_forced(oracle):
+    """The time-blocked, ghost-zone tiled kernel (K2b, for tables wider than 16384 diagonals) forced on tables the
+    oracle can check: several tiles x dozens of time blocks, all end rules, int32 / f64 / generic."""
+    from biseqt_amd import synth, _pwlib as W
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(77)
+    o = synth.rand_seqs(rng, 1, 1500)[0]
+    m = synth.mutate(rng, o, 0.08, 0.04, 0.4)
+    o2 = synth.rand_seqs(rng, 1, 900)[0]
+    m2 = np.concatenate([synth.rand_seqs(rng, 1, 700)[0], synth.mutate(rng, o2[200:], 0.05, 0.03, 0.3)])
+    cases = [
+        (o, m, dict(mode=0, alntype=1), 0),                                  # STD LOCAL: 5 tiles
+        (o, m, dict(mode=0, alntype=0), 0),                                  # STD GLOBAL
+        (o2, m2, dict(mode=0, alntype=4), 0),                                # STD OVERLAP
+        (o2, m2, dict(mode=0, alntype=2), W.PW_FLAG_FORCE_F64),              # START_ANCHORED, f64
+        (o, m, dict(mode=1, alntype=1, diag_range=(-700, 900)), 0),          # B_LOCAL
+        (o, m, dict(mode=1, alntype=2, diag_range=(-1200, 300)), W.PW_FLAG_FORCE_GENERIC),   # B_OVERLAP, generic
+        (o[:37], m[:41], dict(mode=0, alntype=1), 0),                        # a single small tile
+    ]
+    for o_, m_, kw, flags in cases:
+        bkw = dict(alnmode=kw['mode'], alntype=kw['alntype'], alphabet_len=4, match_score=1, mismatch_score=-3,
+                   go_score=-5, ge_score=-2, flags=flags | W.PW_FLAG_FORCE_TILED)
+        if 'diag_range' in kw:
+            bkw['diag_range'] = kw['diag_range']
+        with BatchAligner([(o_, m_), (m_[:300], o_[:400])] if kw['mode'] == 0 else [(o_, m_)], **bkw) as b:
+            assert 'tile' in b.kernel_name
+            res = b.run()
+            txs = b.transcripts(res)
+        r = oracle.solve(o_, m_, L=4, match=1, mismatch=-3, go=-5, ge=-2, **kw)
+        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'], kw
+        if r['opt'][0] != -1:
+            assert res['score'][0] == r['score'], kw
+            if not r['would_panick'] and not r['tb_null']:
+                assert txs[0] == r['transcript'], kw
+                assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
+        if kw['mode'] == 0:
+            r2 = oracle.solve(m_[:300], o_[:400], L=4, match=1, mismatch=-3, go=-5, ge=-2, **kw)
+            assert (res['opt_i'][1], res['opt_j'][1]) == r2['opt'], kw
+            if r2['opt'][0] != -1:
+                assert res['score'][1] == r2['score'], kw
+                if not r2['would_panick'] and not r2['tb_null']:
+                    assert txs[1] == r2['transcript'], kw
