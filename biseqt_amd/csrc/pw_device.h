@@ -36,7 +36,49 @@ struct DevP {
   PW_FN static int lane0() { return 0; }
   PW_FN static bool central() { return true; }
   static constexpr bool kVirtualLanes = false;
+  static constexpr bool kBatchedShifts = false;
 };
+
+// N values moved by one lane across a workgroup that is one long row of lanes: DPP inside each wavefront, one
+// LDS slot set per wavefront edge and ONE barrier for the group.  `phase` alternates between two slot sets, so
+// a wavefront that is already writing exchange e + 1 never overwrites what a slower one still reads from e
+// (exchange e + 1's own barrier orders e's reads before e + 2's writes).
+template <int N, int MAXW> PW_FN void wg_shift_right(int32_t* v, const int32_t* old, int phase) {
+  __shared__ int32_t edge[2][MAXW][N];
+  const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
+  int32_t r[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = __builtin_amdgcn_update_dpp(old[i], v[i], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  if (l == 63) {
+#pragma unroll
+    for (int i = 0; i < N; i++) edge[phase][w][i] = v[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (l == 0 && w > 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = edge[phase][w - 1][i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = r[i];
+}
+template <int N, int MAXW> PW_FN void wg_shift_left(int32_t* v, const int32_t* old, int phase) {
+  __shared__ int32_t edge[2][MAXW][N];
+  const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u), nw = (int)(blockDim.x >> 6);
+  int32_t r[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) r[i] = __builtin_amdgcn_update_dpp(old[i], v[i], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) edge[phase][w][i] = v[i];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if (l == 63 && w + 1 < nw) {
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = edge[phase][w + 1][i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = r[i];
+}
 
 // Platform policy for bands wider than one wavefront holds: a workgroup of blockDim.x / 64 wavefronts is one
 // long row of lanes.  Inside a wavefront the shifts are the same DPP moves; the value that crosses a wavefront
@@ -47,6 +89,9 @@ struct DevPM {
   PW_FN static int lane0() { return 0; }
   PW_FN static bool central() { return true; }
   static constexpr bool kVirtualLanes = false;
+  static constexpr bool kBatchedShifts = true;
+  template <int N> PW_FN static void shrv(int32_t* v, const int32_t* old, int phase) { wg_shift_right<N, 16>(v, old, phase); }
+  template <int N> PW_FN static void shlv(int32_t* v, const int32_t* old, int phase) { wg_shift_left<N, 16>(v, old, phase); }
   PW_FN static int nlanes() { return (int)blockDim.x; }
   PW_FN static int nwaves() { return (int)(blockDim.x >> 6); }
   PW_FN static int32_t shr1(int32_t v, int32_t old) {
@@ -116,7 +161,7 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int
 // Platform policy of a TILE of the time-blocked single-pair kernel (K2b): a workgroup of kTileLanes lanes whose
 // lane indices are global (tile * kTileCentral - kTileGhost + thread); the first kTileGhost and the last
 // kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.
-constexpr int kTileLanes = 256, kTileGhost = 32, kTileCentral = kTileLanes - 2 * kTileGhost;
+constexpr int kTileLanes = PW_TILE_LANES, kTileGhost = PW_TILE_GHOST, kTileCentral = kTileLanes - 2 * kTileGhost;
 struct DevPT {
   PW_FN static int lane0() { return (int)blockIdx.x * kTileCentral - kTileGhost; }
   PW_FN static int lane() { return lane0() + (int)threadIdx.x; }
@@ -124,6 +169,20 @@ struct DevPT {
   PW_FN static int nwaves() { return kTileLanes / 64; }
   PW_FN static bool central() { return (int)threadIdx.x >= kTileGhost && (int)threadIdx.x < kTileLanes - kTileGhost; }
   static constexpr bool kVirtualLanes = true;
+  static constexpr bool kBatchedShifts = true;
+  template <int N> PW_FN static void shrv(int32_t* v, const int32_t* old, int phase) { wg_shift_right<N, kTileLanes / 64>(v, old, phase); }
+  template <int N> PW_FN static void shlv(int32_t* v, const int32_t* old, int phase) { wg_shift_left<N, kTileLanes / 64>(v, old, phase); }
+  // workgroup-wide maxima of four integers
+  PW_FN static void wg_max4(int (&v)[4]) {
+    __shared__ int red[4];
+    if (threadIdx.x < 4) red[threadIdx.x] = -0x7fffffff;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) atomicMax(&red[i], v[i]);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = red[i];
+  }
   PW_FN static int32_t shr1(int32_t v, int32_t old) {
     __shared__ int32_t edge[kTileLanes / 64];
     const int w = (int)(threadIdx.x >> 6), l = (int)(threadIdx.x & 63u);
@@ -149,7 +208,7 @@ struct DevPT {
   PW_FN static int32_t wave_bcast(int32_t v, int) { return v; }     // (the tile kernel has no in-kernel end search)
 };
 
-constexpr int kTileBK = 4;     // diagonals per lane of the tiled kernel: 768 centre diagonals, 128 ghost steps per launch
+constexpr int kTileBK = PW_TILE_BK;     // diagonals per lane of the tiled kernel (default 2 x 128 centre lanes = 256 centre diagonals, 64 ghost lanes = 128 steps per launch)
 static_assert(kTileBK == kTileBKHost && kTileCentral == kTileCentralLanes && kTileBlocks * 16 <= kTileGhost * kTileBK,
               "tile geometry: host and device must agree, and a time block must fit the ghost zone");
 

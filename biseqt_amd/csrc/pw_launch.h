@@ -30,7 +30,20 @@ static const int kMaxWavesPerPair = 8;
 hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st);
 hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int nw, int nblocks, hipStream_t st);
 // tiled single-pair kernel (K2b): tiles of kTileCentralDiags diagonals + ghosts, time blocks of kTileBlocks blocks
-static const int kTileBKHost = 4, kTileCentralLanes = 192, kTileBlocks = 8;   // must match pw_device.h (checked there)
+// (geometry overridable at build time for tuning runs: -DPW_TILE_LANES= -DPW_TILE_BK= -DPW_TILE_GHOST= -DPW_TILE_BLOCKS=)
+#ifndef PW_TILE_LANES
+#define PW_TILE_LANES 256
+#endif
+#ifndef PW_TILE_BK
+#define PW_TILE_BK 2
+#endif
+#ifndef PW_TILE_GHOST
+#define PW_TILE_GHOST 64
+#endif
+#ifndef PW_TILE_BLOCKS
+#define PW_TILE_BLOCKS (PW_TILE_GHOST * PW_TILE_BK / 16)
+#endif
+static const int kTileBKHost = PW_TILE_BK, kTileCentralLanes = PW_TILE_LANES - 2 * PW_TILE_GHOST, kTileBlocks = PW_TILE_BLOCKS;
 hipError_t launch_tile(const FillParams<int32_t>& a, int variant, int pair, int ntiles, hipStream_t st);
 hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int ntiles, hipStream_t st);
 hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st);

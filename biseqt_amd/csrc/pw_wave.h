@@ -67,6 +67,33 @@ template <class P> PW_FN double xshl1(double v, double old) {
   r.i[0] = P::shl1(a.i[0], o.i[0]); r.i[1] = P::shl1(a.i[1], o.i[1]);
   return r.d;
 }
+// A score and a 32-bit word moved by one lane in ONE exchange (policies whose shifts cross wavefronts through
+// LDS pay one barrier for the group instead of two per value; `phase` alternates their LDS slots).
+template <class P, int N> PW_FN void xshrv(int32_t (&v)[N], const int32_t (&old)[N], int phase) {
+  if constexpr (P::kBatchedShifts) P::template shrv<N>(v, old, phase);
+  else {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = P::shr1(v[i], old[i]);
+  }
+}
+template <class P, int N> PW_FN void xshlv(int32_t (&v)[N], const int32_t (&old)[N], int phase) {
+  if constexpr (P::kBatchedShifts) P::template shlv<N>(v, old, phase);
+  else {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = P::shl1(v[i], old[i]);
+  }
+}
+template <class P, bool LEFT> PW_FN void xshift_pair(int32_t& s, int32_t sold, uint32_t& w, uint32_t wold, int phase) {
+  int32_t v[2] = {s, (int32_t)w}; const int32_t o[2] = {sold, (int32_t)wold};
+  if (LEFT) xshlv<P, 2>(v, o, phase); else xshrv<P, 2>(v, o, phase);
+  s = v[0]; w = (uint32_t)v[1];
+}
+template <class P, bool LEFT> PW_FN void xshift_pair(double& s, double sold, uint32_t& w, uint32_t wold, int phase) {
+  D2I a, b; a.d = s; b.d = sold;
+  int32_t v[3] = {a.i[0], a.i[1], (int32_t)w}; const int32_t o[3] = {b.i[0], b.i[1], (int32_t)wold};
+  if (LEFT) xshlv<P, 3>(v, o, phase); else xshrv<P, 3>(v, o, phase);
+  a.i[0] = v[0]; a.i[1] = v[1]; s = a.d; w = (uint32_t)v[2];
+}
 template <class P> PW_FN int32_t xshfl_xor(int32_t v, int m) { return P::shfl_xor(v, m); }
 template <class P> PW_FN double xshfl_xor(double v, int m) {
   D2I a, r; a.d = v;
@@ -236,26 +263,28 @@ struct WaveFill {
   // One iteration = the even step 2*it and the odd step 2*it + 1.
   template <bool RAMP>
   PW_FN void iteration(int it, int k) {
-    // even step: slot 0 takes its "up" offer from the previous lane's last slot
-    T uin = xshr1<P>(U[BK - 1], Tr::neg());
+    // even step: slot 0 takes its "up" offer from the previous lane's last slot (moved at the end of the
+    // previous iteration, together with the mutant window)
+    T uin = uin_next;
     if (P::kVirtualLanes) uin = lane == 0 ? Tr::neg() : uin;    // nothing lies below diagonal 0 of the band
     EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
-    // the origin window moves on by one letter: lane l takes lane l+1's lowest letter, the last lane
-    // is fed from the arena
+    // one exchange to the left: the origin window moves on by one letter (lane l takes lane l+1's lowest
+    // letter, the last lane is fed from the arena) and the last slot gets its "left" offer for the odd step
+    T lin = L[0];
     {
-      const uint32_t feed = feed_byte(fo_lo, fo_hi, k);
-      const uint32_t oin = xshl1<P>(ow[0], feed);
+      uint32_t oin = ow[0];
+      xshift_pair<P, true>(lin, Tr::neg(), oin, feed_byte(fo_lo, fo_hi, k), it & 1);
 #pragma unroll
       for (int i = 0; i + 1 < R; i++) ow[i] = ow[i + 1];
       ow[R - 1] = oin;
     }
-    // odd step: the last slot takes its "left" offer from the next lane's slot 0
-    const T lin = xshl1<P>(L[0], Tr::neg());
     OddLoop<RAMP, 0>::run(*this, lin, 2 * it + 1);
-    // the mutant window moves on: lane l takes lane l-1's highest letter, lane 0 is fed from the arena
+    // one exchange to the right: the mutant window moves on (lane l takes lane l-1's highest letter, lane 0
+    // is fed from the arena) and the next even step's "up" offer travels with it
     {
-      const uint32_t feed = feed_byte(fm_lo, fm_hi, k);
-      const uint32_t min_ = xshr1<P>(mw[R - 1], feed);
+      uint32_t min_ = mw[R - 1];
+      uin_next = U[BK - 1];
+      xshift_pair<P, false>(uin_next, Tr::neg(), min_, feed_byte(fm_lo, fm_hi, k), it & 1);
 #pragma unroll
       for (int i = R - 1; i > 0; i--) mw[i] = mw[i - 1];
       mw[0] = min_;
@@ -269,6 +298,7 @@ struct WaveFill {
   // BLOCK AHEAD (feed_issue) and funnel-shifted into two registers when the block starts (feed_commit),
   // so no iteration ever waits on memory.  Word indices are clamped: letters outside the sequence feed
   // only cells outside the table.
+  T uin_next;                 // slot 0's "up" offer for the next even step
   int xfeed_o, yfeed_m;       // arena index the edge lanes are fed from at iteration 0
   int owlast, mwlast;         // last dword of each frame
   uint32_t fo_lo, fo_hi, fm_lo, fm_hi;                 // the current block's 8 + 8 letters
@@ -322,6 +352,7 @@ struct WaveFill {
     olast = X > 0 ? X - 1 : 0; mlast = Y > 0 ? Y - 1 : 0;
     owlast = olast >> 2; mwlast = mlast >> 2;
     njl = lane < 0 ? 0 : ndiag - lane * BK;      // (tiles may carry virtual lanes below diagonal 0)
+    uin_next = Tr::neg();
     // s0 == dmin (mod 2): e, f are exact
     const int e = (pd.s0 + pd.dmin) >> 1;       // x of diagonal dd = 0 on step t = 0
     const int f = (pd.s0 - pd.dmin) >> 1;       // y of diagonal dd = 0 on step t = 0
@@ -362,10 +393,45 @@ struct WaveFill {
   // tile_nb * 16 <= ghost * BK steps the centre lanes (P::central()) are still exact; only they store masks
   // and hand their state to the next time block.  State: [5][st_pitch] = H, U, L, best, bestT per diagonal.
   PW_FN void run_tile() {
-    const int b0 = a.tile_b0;
-    init(8 * b0);
-    const int pitch = a.st_pitch;
-    if (b0 > 0) {
+    const int bb0 = a.tile_b0, bb1 = a.tile_b0 + a.tile_nb, pitch = a.st_pitch;
+    lane = P::lane();
+    ndiag = pd.ndiag;
+    // steps on which this tile's in-band diagonals (ghost lanes included) hold their first / last cell
+    int w4[4] = {-0x7fffffff, -0x7fffffff, -0x7fffffff, -0x7fffffff};   // max of: -tf, tf, -tl, tl
+#pragma unroll
+    for (int j = 0; j < BK; j++) {
+      const int dd = lane * BK + j;
+      if (lane >= 0 && dd < ndiag) {
+        const int d = pd.dmin + dd;
+        const int tf = (d < 0 ? -d : d) - pd.s0;
+        const int tl = tf + 2 * ((d > 0 ? 0 : d) + (pd.X - d > pd.Y ? pd.Y : pd.X - d));
+        w4[0] = -tf > w4[0] ? -tf : w4[0]; w4[1] = tf > w4[1] ? tf : w4[1];
+        w4[2] = -tl > w4[2] ? -tl : w4[2]; w4[3] = tl > w4[3] ? tl : w4[3];
+      }
+    }
+    P::wg_max4(w4);
+    const int tfmin = -w4[0], tfmax = w4[1], tlmin = -w4[2], tlmax = w4[3];
+    // the blocks of this time block in which any of them is live
+    int bA = tfmin >> 4, bB = tlmax >> 4;
+    if (w4[1] == -0x7fffffff) { bA = 1; bB = 0; }          // no diagonal of the band in this tile
+    bA = bA < bb0 ? bb0 : bA; bB = bB > bb1 - 1 ? bb1 - 1 : bB;
+    if (bA > bB) {
+      // not started yet or already finished: the state passes through unchanged
+      if (P::central()) {
+#pragma unroll
+        for (int j = 0; j < BK; j++) {
+          const int dd = lane * BK + j;
+          if (lane >= 0 && dd < ndiag) {
+#pragma unroll
+            for (int r = 0; r < 5; r++)
+              a.st_out[r * pitch + dd] = bb0 > 0 ? a.st_in[r * pitch + dd] : (r == 4 ? T(0) : Tr::neg());
+          }
+        }
+      }
+      return;
+    }
+    init(8 * bA);
+    if (bb0 > 0) {
 #pragma unroll
       for (int j = 0; j < BK; j++) {
         const int dd = lane * BK + j;
@@ -374,12 +440,17 @@ struct WaveFill {
           best[j] = a.st_in[3 * pitch + dd]; bestT[j] = (int32_t)a.st_in[4 * pitch + dd];
         }
       }
+      uint32_t none = 0;
+      uin_next = U[BK - 1];
+      xshift_pair<P, false>(uin_next, Tr::neg(), none, 0u, 1);
     }
-    feed_issue(b0);
-    for (int b = b0; b < b0 + a.tile_nb; b++) {
+    feed_issue(bA);
+    for (int b = bA; b <= bB; b++) {
       feed_commit(b);
-      if (b + 1 < b0 + a.tile_nb) feed_issue(b + 1);
-      block<true>(b);          // the predicated body everywhere (first version: exact, not yet tuned)
+      if (b < bB) feed_issue(b + 1);
+      // steady: every diagonal of the tile started strictly before the block and none ends inside it
+      if (16 * b > tfmax && 16 * b + 15 <= tlmin) block<false>(b);
+      else block<true>(b);
       store_masks(b);
     }
     if (P::central()) {

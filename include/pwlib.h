@@ -120,8 +120,8 @@ typedef struct alignment {
 // dptable_init: computes table dimensions exactly as the reference does (clamps the band in place and
 // prints the same messages to stdout, rejects infeasible banded-global problems), allocates
 // num_rows / row_lens / the host cell rows (all cells empty).  Returns 0, or -1 on error -- also for
-// problems this library does not support (max_new_mins > 0, letters >= 256, a band wider than the
-// widest kernel: 16384 diagonals): it fails loudly on stderr, it never falls back to a CPU path.
+// problems this library does not support (max_new_mins > 0, letters >= 256, a band or table wider than
+// 2^21 diagonals): it fails loudly on stderr, it never falls back to a CPU path.
 int dptable_init(dptable* T);
 
 // dptable_free: releases everything dptable_init / dptable_solve / dptable_traceback allocated for T,

@@ -84,6 +84,7 @@ struct EmuP {
   static int lane0() { return 0; }
   static bool central() { return true; }
   static constexpr bool kVirtualLanes = false;
+  static constexpr bool kBatchedShifts = false;
 };
 
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>

