@@ -164,11 +164,14 @@ int batch_build(pw_batch* b) {
   else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
-  // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16
+  // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16.  The
+  // score bound is 8000, not 16000: the first diagonal above the band is computed like any other and its offer
+  // into the band is lowered by only 8192 (the sentinel), so no score -- in or out of the band -- may reach that
+  // (regression: test_band_edge_never_leaks_long_pairs).
   int pbk = 0, pnl = 0, pseg = 0;
   if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED)) && maxnd <= 2048 &&
-      nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 16000 && maxspan < 32000 && b->ge <= 0) {
+      nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 8000 && maxspan < 32000 && b->ge <= 0) {
     // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
     // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
     // 64 x BK diagonal slots busy.  Packing is chosen when it buys at least 25 % more busy slots.

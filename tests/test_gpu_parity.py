@@ -479,3 +479,22 @@ def test_config3_full_size_properties():
     assert s == res['score'][0] and s > 30000
     assert (i, j) == (int(res['opt_i'][0]), int(res['opt_j'][0]))
     assert tx[0] in 'MS' and tx[-1] in 'MS'                  # a local alignment never starts or ends with a gap
+
+
+def test_band_edge_never_leaks_long_pairs(oracle):
+    """The true alignment lies exactly on the first diagonal OUTSIDE the band (origin == mutant, band (-21, -1)):
+    nothing of that diagonal's ~9000-long perfect run may leak into the band.  (The 16-bit kernel's band-edge
+    block is only 8192 deep, so pairs this long must take the 32-bit kernel.)"""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(91)
+    o = synth.rand_seqs(rng, 1, 9000)[0]
+    for band in ((-21, -1), (1, 23)):
+        with BatchAligner([(o, o.copy())] * 3, alnmode=1, alntype=1, alphabet_len=4, diag_range=band,
+                          match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as b:
+            res = b.run()
+            txs = b.transcripts(res)
+        r = oracle.solve(o, o, L=4, mode=1, alntype=1, diag_range=band, match=1, mismatch=-3, go=-5, ge=-2)
+        for k in range(3):
+            assert res['score'][k] == r['score'] and (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (band, res[k], r['score'])
+            assert txs[k] == r['transcript']
