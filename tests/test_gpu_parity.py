@@ -5,6 +5,7 @@ scores the comparison is also exact (same IEEE double additions in the same asso
 stricter than the 3-decimals the reference's own tests ask for (tests/test_pw.py:126-135)."""
 import collections
 import json
+import os
 
 import numpy as np
 import pytest
@@ -498,3 +499,17 @@ def test_band_edge_never_leaks_long_pairs(oracle):
         for k in range(3):
             assert res['score'][k] == r['score'] and (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (band, res[k], r['score'])
             assert txs[k] == r['transcript']
+
+
+def test_adversarial_fuzz_vs_oracle(oracle):
+    """A bounded run of tests/micro/fuzz_gpu.py: random batches over all modes / types / score sets / kernel-forcing
+    flags with adversarial pair shapes (alignments on and next to band edges, identical and shifted copies,
+    repeats, empty sequences, clamped and infeasible bands), every pair compared with the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('fuzz_gpu', os.path.join(os.path.dirname(__file__), 'micro', 'fuzz_gpu.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    nb, npairs, nbad = fz.run(60, 20261004, max_batches=400)
+    assert nbad == 0 and npairs > 1000
+    nb, npairs, nbad = fz.run(60, 20261005, long_mode=True, max_batches=25)
+    assert nbad == 0
