@@ -120,6 +120,10 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
            'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_fill_ms',
            'pw_batch_trace_ms']
+# every symbol include/pw_seeds.h declares
+SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_seeds_is_self', 'pw_seeds_rows_device',
+                'pw_seeds_rows', 'pw_seeds_count', 'pw_seeds_kmers', 'pw_seeds_build_ms',
+                'pw_seeds_algorithmic_bytes', 'pw_seeds_destroy', 'pw_seeds_last_error']
 
 
 def check_layout():
@@ -186,6 +190,28 @@ def load():
     lib.pw_batch_fill_ms.restype = C.c_float
     lib.pw_batch_trace_ms.argtypes = [C.c_void_p]
     lib.pw_batch_trace_ms.restype = C.c_float
+    # include/pw_seeds.h
+    lib.pw_seeds_create.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                    P(C.c_uint64), C.c_int, C.c_int]
+    lib.pw_seeds_create.restype = C.c_void_p
+    lib.pw_seeds_build.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.pw_seeds_num_rows.argtypes = [C.c_void_p]
+    lib.pw_seeds_num_rows.restype = C.c_int64
+    lib.pw_seeds_is_self.argtypes = [C.c_void_p]
+    lib.pw_seeds_rows_device.argtypes = [C.c_void_p]
+    lib.pw_seeds_rows_device.restype = C.c_void_p
+    lib.pw_seeds_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.pw_seeds_count.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int, C.c_int32, C.c_int32]
+    lib.pw_seeds_count.restype = C.c_int64
+    lib.pw_seeds_kmers.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.pw_seeds_kmers.restype = C.c_int64
+    lib.pw_seeds_build_ms.argtypes = [C.c_void_p]
+    lib.pw_seeds_build_ms.restype = C.c_double
+    lib.pw_seeds_algorithmic_bytes.argtypes = [C.c_void_p]
+    lib.pw_seeds_algorithmic_bytes.restype = C.c_int64
+    lib.pw_seeds_destroy.argtypes = [C.c_void_p]
+    lib.pw_seeds_destroy.restype = None
+    lib.pw_seeds_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 

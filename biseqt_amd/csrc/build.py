@@ -55,6 +55,9 @@ def _jobs():
     obj = os.path.join(OBJ_DIR, 'pw_trace.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_trace.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_trace.hip')]))
+    obj = os.path.join(OBJ_DIR, 'pw_seeds.o')
+    jobs.append((obj, [HIPCC] + COMMON + ['-Wno-unused-parameter', '-c', os.path.join(HERE, 'pw_seeds.hip'), '-o', obj],
+                 [os.path.join(HERE, 'pw_seeds.hip'), os.path.join(ROOT, 'include', 'pw_seeds.h')]))
     obj = os.path.join(OBJ_DIR, 'pwlib_api.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-x', 'hip', '-c', os.path.join(HERE, 'pwlib_api.cpp'), '-o', obj],
                  [os.path.join(HERE, 'pwlib_api.cpp'), os.path.join(ROOT, 'include', 'pwlib.h'),

@@ -1,0 +1,337 @@
+// pw_seeds.hip -- exact-match k-mer seeds of one pair of sequences on gfx950 (C ABI: include/pw_seeds.h).
+//
+// What the reference does with SQLite tables and Python generators (kmers.py:437-509, seeds.py:117-237) is a
+// sort-merge join:
+//   K5a k_encode   one thread per position: the k-mer as an integer in base L (kmers.py:164-210), or the
+//                  "masked" key L^k when its letter set equals a mask set (kmers.py:232-236)
+//       sort       (k-mer, position) of S and of T by k-mer -- stable LSD radix sort (rocPRIM), so positions stay
+//                  ascending inside a k-mer, which is the reference's (seqid, pos) hit order
+//   K5b k_match    one thread per sorted S element: its run of equal k-mers in T (two binary searches) -> the
+//                  number of rows it contributes; exclusive scan -> row offsets
+//   K5c k_expand   one thread per row: (d, a) = (i - j, i + j).  Rows come out in the reference's rowid order
+//                  (k-mer asc, i asc, j asc) by construction, with no further sort
+//   K5d k_count    COUNT(*) in a (d, a) band: predicate + wave reduction + one atomic per wave
+// A self comparison (seeds.py:33,141-143) joins S with itself: per k-mer run the pairs i < j in combination
+// order, then the trivial pairs -- an element contributes the pairs with the later elements of its run, and the
+// LAST element of a run contributes the run's trivial rows.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/pw_seeds.h"
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string& s) { g_err = s; }
+#define SD_CHECK(call)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err(std::string(#call) + ": " + hipGetErrorString(e_));                            \
+      return -1;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+constexpr int kMaxMasks = 16;
+struct MaskSets { uint64_t set[kMaxMasks]; int n; };
+
+// ---- K5a ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ seq, int64_t n, int k, int L,
+                                                uint64_t kinv, MaskSets ms, uint64_t* __restrict__ keys,
+                                                uint32_t* __restrict__ pos) {
+  __shared__ uint8_t tile[256 + 64];
+  const int64_t base = (int64_t)blockIdx.x * 256;
+  const int64_t nk = n - k + 1;
+  for (int t = (int)threadIdx.x; t < 256 + k - 1; t += 256) {
+    const int64_t p = base + t;
+    tile[t] = p < n ? seq[p] : 0;
+  }
+  __syncthreads();
+  const int64_t p = base + threadIdx.x;
+  if (p >= nk) return;
+  uint64_t v = 0, lets = 0;
+  for (int t = 0; t < k; t++) {
+    const uint32_t c = tile[threadIdx.x + t];
+    v = v * (uint64_t)L + c;
+    lets |= 1ull << c;
+  }
+  bool masked = false;
+  for (int i = 0; i < ms.n; i++) masked |= lets == ms.set[i];
+  keys[p] = masked ? kinv : v;
+  pos[p] = (uint32_t)p;
+}
+
+__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int64_t upper_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// ---- K5b ------------------------------------------------------------------------------------------------
+// other = sorted keys of T (or of S itself for a self comparison)
+__global__ __launch_bounds__(256) void k_match(const uint64_t* __restrict__ ks, int64_t ns,
+                                               const uint64_t* __restrict__ other, int64_t no, uint64_t kinv,
+                                               int self, uint32_t* __restrict__ lo_out, uint64_t* __restrict__ cnt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ns) return;
+  const uint64_t key = ks[e];
+  if (key >= kinv) { lo_out[e] = 0; cnt[e] = 0; return; }
+  const int64_t lo = lower_bound_u64(other, no, key);
+  const int64_t hi = upper_bound_u64(other, no, key);
+  lo_out[e] = (uint32_t)lo;
+  if (!self) cnt[e] = (uint64_t)(hi - lo);
+  else cnt[e] = (uint64_t)(hi - 1 - e) + (e == hi - 1 ? (uint64_t)(hi - lo) : 0ull);
+}
+
+// ---- K5c ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand(const uint64_t* __restrict__ off, int64_t ns, int64_t nrows,
+                                                const uint32_t* __restrict__ ps, const uint32_t* __restrict__ po,
+                                                const uint32_t* __restrict__ lo_in, const uint64_t* __restrict__ ks,
+                                                int self, int2* __restrict__ rows) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= nrows) return;
+  const int64_t e = upper_bound_u64(off, ns, (uint64_t)o) - 1;      // last element whose first row is <= o
+  const int64_t r = o - (int64_t)off[e];
+  int32_t i, j;
+  if (!self) {
+    i = (int32_t)ps[e];
+    j = (int32_t)po[(int64_t)lo_in[e] + r];
+  } else {
+    // the run of e is [lo, hi): e pairs with e + 1 .. hi - 1; the last element of the run then lists (x, x)
+    const int64_t lo = lo_in[e];
+    const uint64_t key = ks[e];
+    const bool last = e + 1 >= ns || ks[e + 1] != key;
+    if (!last) { i = (int32_t)ps[e]; j = (int32_t)ps[e + 1 + r]; }
+    else { i = (int32_t)ps[lo + r]; j = i; }
+  }
+  rows[o] = make_int2(i - j, i + j);
+}
+
+// ---- K5d ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count(const int2* __restrict__ rows, int64_t nrows, int have_d, int dmin,
+                                               int dmax, int have_a, int amin, int amax,
+                                               unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < nrows; o += (int64_t)gridDim.x * 256) {
+    const int2 r = rows[o];
+    const bool ok = (!have_d || (r.x >= dmin && r.x <= dmax)) && (!have_a || (r.y >= amin && r.y <= amax));
+    c += ok ? 1ull : 0ull;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) c += __shfl_xor(c, s, 64);
+  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
+}
+
+__global__ void k_total(const uint64_t* __restrict__ off, const uint64_t* __restrict__ cnt, int64_t ns,
+                        unsigned long long* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ns > 0 ? off[ns - 1] + cnt[ns - 1] : 0ull;
+}
+
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    SD_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+    cap = bytes;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct pw_seed_index {
+  int device = 0, L = 0, k = 0, self = 0, bits = 0;
+  int64_t nS = 0, nT = 0, nkS = 0, nkT = 0, nrows = -1;
+  uint64_t kinv = 0;
+  MaskSets ms;
+  DevBuf dS, dT, keys_in, keys_s, keys_t, pos_in, pos_s, pos_t, lo, cnt, off, rows, tmp, scalar;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms_build = 0.f;
+};
+
+extern "C" {
+
+const char* pw_seeds_last_error(void) { return g_err.c_str(); }
+
+pw_seed_index* pw_seeds_create(int device, const uint8_t* S, int64_t nS, const uint8_t* T, int64_t nT,
+                               int alphabet_len, int wordlen, const uint64_t* mask_sets, int n_masks,
+                               int self_comp) {
+  if (alphabet_len < 1 || alphabet_len > 36) { set_err("alphabet_len must be 1..36 (kmers.py:266)"); return nullptr; }
+  if (wordlen < 1 || wordlen > 31) { set_err("wordlen must be 1..31 (kmers.py:269)"); return nullptr; }
+  if (n_masks < 0 || n_masks > kMaxMasks) { set_err("at most 16 mask sets"); return nullptr; }
+  if (nS < 0 || nT < 0 || nS >= (1ll << 31) || nT >= (1ll << 31)) { set_err("sequence length out of range"); return nullptr; }
+  // L^k must fit: the masked key is L^k itself
+  long double lk = 1; for (int i = 0; i < wordlen; i++) lk *= alphabet_len;
+  if (lk >= (long double)(1ull << 62)) { set_err("alphabet_len ^ wordlen must be below 2^62"); return nullptr; }
+  for (int64_t i = 0; i < nS; i++) if (S[i] >= alphabet_len) { set_err("letter outside the alphabet in S"); return nullptr; }
+  if (self_comp < 0) self_comp = (nS == nT && (nS == 0 || memcmp(S, T, (size_t)nS) == 0)) ? 1 : 0;
+  if (!self_comp) for (int64_t i = 0; i < nT; i++) if (T[i] >= alphabet_len) { set_err("letter outside the alphabet in T"); return nullptr; }
+  if (hipSetDevice(device) != hipSuccess) { set_err("hipSetDevice failed"); return nullptr; }
+  pw_seed_index* x = new pw_seed_index();
+  x->device = device; x->L = alphabet_len; x->k = wordlen; x->self = self_comp;
+  x->nS = nS; x->nT = self_comp ? nS : nT;
+  x->nkS = nS >= wordlen ? nS - wordlen + 1 : 0;
+  x->nkT = self_comp ? x->nkS : (nT >= wordlen ? nT - wordlen + 1 : 0);
+  uint64_t kinv = 1; for (int i = 0; i < wordlen; i++) kinv *= (uint64_t)alphabet_len;
+  x->kinv = kinv;
+  x->bits = 1; while ((kinv >> x->bits) != 0) x->bits++;
+  x->ms.n = n_masks;
+  for (int i = 0; i < kMaxMasks; i++) x->ms.set[i] = i < n_masks ? mask_sets[i] : 0;
+  auto fail = [&](const char* what) { if (g_err.empty()) set_err(what); pw_seeds_destroy(x); return (pw_seed_index*)nullptr; };
+  if (x->dS.ensure((size_t)nS + 64) != 0) return fail("hipMalloc");
+  if (nS && hipMemcpy(x->dS.p, S, (size_t)nS, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D of S failed");
+  if (!self_comp) {
+    if (x->dT.ensure((size_t)nT + 64) != 0) return fail("hipMalloc");
+    if (nT && hipMemcpy(x->dT.p, T, (size_t)nT, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D of T failed");
+  }
+  if (hipEventCreate(&x->ev0) != hipSuccess || hipEventCreate(&x->ev1) != hipSuccess) return fail("hipEventCreate");
+  return x;
+}
+
+static int encode_sort(pw_seed_index* x, const uint8_t* seq, int64_t n, int64_t nk, DevBuf& keys_out, DevBuf& pos_out,
+                       hipStream_t st) {
+  if (keys_out.ensure((size_t)std::max<int64_t>(nk, 1) * 8) != 0 || pos_out.ensure((size_t)std::max<int64_t>(nk, 1) * 4) != 0) return -1;
+  if (nk <= 0) return 0;
+  if (x->keys_in.ensure((size_t)nk * 8) != 0 || x->pos_in.ensure((size_t)nk * 4) != 0) return -1;
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, seq, n, x->k, x->L, x->kinv, x->ms,
+                     (uint64_t*)x->keys_in.p, (uint32_t*)x->pos_in.p);
+  size_t tb = 0;
+  SD_CHECK(rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)x->keys_in.p, (uint64_t*)keys_out.p,
+                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
+                                     (unsigned)x->bits, st));
+  if (x->tmp.ensure(tb) != 0) return -1;
+  SD_CHECK(rocprim::radix_sort_pairs(x->tmp.p, tb, (const uint64_t*)x->keys_in.p, (uint64_t*)keys_out.p,
+                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
+                                     (unsigned)x->bits, st));
+  return 0;
+}
+
+int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
+  if (!x) { set_err("null index"); return -1; }
+  hipStream_t st = (hipStream_t)stream;
+  SD_CHECK(hipSetDevice(x->device));
+  if (max_rows <= 0) max_rows = (1ll << 31) - 1;
+  x->nrows = -1;
+  SD_CHECK(hipEventRecord(x->ev0, st));
+  if (encode_sort(x, (const uint8_t*)x->dS.p, x->nS, x->nkS, x->keys_s, x->pos_s, st) != 0) return -1;
+  if (!x->self && encode_sort(x, (const uint8_t*)x->dT.p, x->nT, x->nkT, x->keys_t, x->pos_t, st) != 0) return -1;
+  const int64_t ns = x->nkS;
+  if (x->scalar.ensure(16) != 0) return -1;
+  unsigned long long total = 0;
+  if (ns > 0) {
+    if (x->lo.ensure((size_t)ns * 4) != 0 || x->cnt.ensure((size_t)ns * 8) != 0 || x->off.ensure((size_t)ns * 8) != 0) return -1;
+    const uint64_t* other = x->self ? (const uint64_t*)x->keys_s.p : (const uint64_t*)x->keys_t.p;
+    const int64_t no = x->self ? ns : x->nkT;
+    hipLaunchKernelGGL(k_match, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, (const uint64_t*)x->keys_s.p, ns,
+                       other, no, x->kinv, x->self, (uint32_t*)x->lo.p, (uint64_t*)x->cnt.p);
+    size_t tb = 0;
+    SD_CHECK(rocprim::exclusive_scan(nullptr, tb, (const uint64_t*)x->cnt.p, (uint64_t*)x->off.p, (uint64_t)0, (size_t)ns,
+                                     rocprim::plus<uint64_t>(), st));
+    if (x->tmp.ensure(tb) != 0) return -1;
+    SD_CHECK(rocprim::exclusive_scan(x->tmp.p, tb, (const uint64_t*)x->cnt.p, (uint64_t*)x->off.p, (uint64_t)0, (size_t)ns,
+                                     rocprim::plus<uint64_t>(), st));
+    hipLaunchKernelGGL(k_total, dim3(1), dim3(64), 0, st, (const uint64_t*)x->off.p, (const uint64_t*)x->cnt.p, ns,
+                       (unsigned long long*)x->scalar.p);
+    SD_CHECK(hipMemcpyAsync(&total, x->scalar.p, 8, hipMemcpyDeviceToHost, st));
+    SD_CHECK(hipStreamSynchronize(st));
+  }
+  if ((int64_t)total > max_rows) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "the seeds table would hold %llu rows (limit %lld): raise max_rows or the word length", total, (long long)max_rows);
+    set_err(msg);
+    return -1;
+  }
+  if (x->rows.ensure((size_t)std::max<unsigned long long>(total, 1) * 8) != 0) return -1;
+  if (total > 0) {
+    hipLaunchKernelGGL(k_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint64_t*)x->off.p, ns,
+                       (int64_t)total, (const uint32_t*)x->pos_s.p,
+                       x->self ? (const uint32_t*)x->pos_s.p : (const uint32_t*)x->pos_t.p, (const uint32_t*)x->lo.p,
+                       (const uint64_t*)x->keys_s.p, x->self, (int2*)x->rows.p);
+  }
+  SD_CHECK(hipEventRecord(x->ev1, st));
+  SD_CHECK(hipEventSynchronize(x->ev1));
+  SD_CHECK(hipEventElapsedTime(&x->ms_build, x->ev0, x->ev1));
+  SD_CHECK(hipGetLastError());
+  x->nrows = (int64_t)total;
+  return 0;
+}
+
+int64_t pw_seeds_num_rows(const pw_seed_index* x) { return x ? x->nrows : -1; }
+int pw_seeds_is_self(const pw_seed_index* x) { return x ? x->self : -1; }
+const int32_t* pw_seeds_rows_device(const pw_seed_index* x) { return (x && x->nrows >= 0) ? (const int32_t*)x->rows.p : nullptr; }
+double pw_seeds_build_ms(const pw_seed_index* x) { return x ? (double)x->ms_build : -1.0; }
+int64_t pw_seeds_algorithmic_bytes(const pw_seed_index* x) {
+  if (!x || x->nrows < 0) return -1;
+  return x->nS + (x->self ? 0 : x->nT) + 8 * x->nrows;
+}
+
+int pw_seeds_rows(const pw_seed_index* x, int32_t* da, int64_t cap) {
+  if (!x || x->nrows < 0) { set_err("pw_seeds_rows before a successful pw_seeds_build"); return -1; }
+  if (cap < x->nrows) { set_err("pw_seeds_rows: capacity too small"); return -1; }
+  SD_CHECK(hipSetDevice(x->device));
+  if (x->nrows) SD_CHECK(hipMemcpy(da, x->rows.p, (size_t)x->nrows * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int64_t pw_seeds_count(const pw_seed_index* x, int have_d, int32_t dmin, int32_t dmax, int have_a, int32_t amin,
+                       int32_t amax) {
+  if (!x || x->nrows < 0) { set_err("pw_seeds_count before a successful pw_seeds_build"); return -1; }
+  if (!have_d && !have_a) return x->nrows;
+  if (x->nrows == 0) return 0;
+  SD_CHECK(hipSetDevice(x->device));
+  unsigned long long* out = (unsigned long long*)x->scalar.p + 1;
+  SD_CHECK(hipMemsetAsync(out, 0, 8, nullptr));
+  const int64_t blocks = std::min<int64_t>((x->nrows + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_count, dim3((unsigned)blocks), dim3(256), 0, nullptr, (const int2*)x->rows.p, x->nrows, have_d,
+                     dmin, dmax, have_a, amin, amax, out);
+  unsigned long long c = 0;
+  SD_CHECK(hipMemcpy(&c, out, 8, hipMemcpyDeviceToHost));
+  return (int64_t)c;
+}
+
+int64_t pw_seeds_kmers(const pw_seed_index* xc, int which, int64_t* out, int64_t cap) {
+  pw_seed_index* x = const_cast<pw_seed_index*>(xc);
+  if (!x) { set_err("null index"); return -1; }
+  const bool t = which != 0 && !x->self;
+  const int64_t n = t ? x->nT : x->nS, nk = t ? x->nkT : x->nkS;
+  if (cap < nk) { set_err("pw_seeds_kmers: capacity too small"); return -1; }
+  if (nk <= 0) return 0;
+  SD_CHECK(hipSetDevice(x->device));
+  DevBuf keys, pos;
+  if (keys.ensure((size_t)nk * 8) != 0 || pos.ensure((size_t)nk * 4) != 0) { keys.release(); pos.release(); return -1; }
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, nullptr,
+                     (const uint8_t*)(t ? x->dT.p : x->dS.p), n, x->k, x->L, x->kinv, x->ms, (uint64_t*)keys.p, (uint32_t*)pos.p);
+  std::vector<uint64_t> h((size_t)nk);
+  const hipError_t e = hipMemcpy(h.data(), keys.p, (size_t)nk * 8, hipMemcpyDeviceToHost);
+  keys.release(); pos.release();
+  if (e != hipSuccess) { set_err("D2H of the k-mers failed"); return -1; }
+  for (int64_t i = 0; i < nk; i++) out[i] = h[(size_t)i] >= x->kinv ? -1 : (int64_t)h[(size_t)i];
+  return nk;
+}
+
+void pw_seeds_destroy(pw_seed_index* x) {
+  if (!x) return;
+  (void)hipSetDevice(x->device);
+  DevBuf* bufs[] = {&x->dS, &x->dT, &x->keys_in, &x->keys_s, &x->keys_t, &x->pos_in, &x->pos_s, &x->pos_t, &x->lo, &x->cnt,
+                    &x->off, &x->rows, &x->tmp, &x->scalar};
+  for (DevBuf* b : bufs) b->release();
+  if (x->ev0) (void)hipEventDestroy(x->ev0);
+  if (x->ev1) (void)hipEventDestroy(x->ev1);
+  delete x;
+}
+
+}  // extern "C"

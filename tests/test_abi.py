@@ -17,7 +17,7 @@ def _declared_functions(header):
     txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     txt = re.sub(r'//[^\n]*', '', txt)
-    return set(re.findall(r'\b(dptable_\w+|pw_\w+)\s*\(', txt)) - {'pw_batch'}
+    return set(re.findall(r'\b(dptable_\w+|pw_\w+)\s*\(', txt)) - {'pw_batch', 'pw_seed_index'}
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -26,6 +26,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert {'dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free'} <= declared
     assert declared == set(W.EXPORTS), declared ^ set(W.EXPORTS)
     for name in declared:
+        assert hasattr(lib, name), name
+    seeds = _declared_functions('pw_seeds.h')
+    assert seeds == set(W.SEED_EXPORTS), seeds ^ set(W.SEED_EXPORTS)
+    for name in seeds:
         assert hasattr(lib, name), name
 
 
