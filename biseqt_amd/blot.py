@@ -1,0 +1,150 @@
+"""Band selection for overlap alignments (host side; mirrors ``biseqt/blot.py``).
+
+What is here: the closed-form geometry and statistics of Word-Blot (``wall_to_wall_distance`` :78-89,
+``expected_overlap_len`` :92-112, ``band_radius`` / ``band_radii`` :116-160, ``H0_moments`` / ``H1_moments``
+:163-218, ``find_peaks`` :37-76) -- scalar arithmetic, evaluated on the host exactly as the reference writes it --
+and ``WordBlotOverlap`` (:490-579), whose heavy part (for every seed, the number of seeds in its diagonal
+neighbourhood, a KD-tree ball query in the reference) runs on the GPU (kernel K6 of pw_seeds.hip).
+``highest_scoring_overlap_band()`` returns the ``d_band`` that the banded overlap aligner
+(``Aligner(..., alnmode=BANDED_MODE, alntype=B_OVERLAP, diag_range=d_band)``) is given.
+"""
+import numpy as np
+from scipy.special import erfcinv
+
+from .seeds import SeedIndex
+
+
+def find_peaks(xs, rs, threshold):
+    """Maximal disjoint bands ``(i - 1, i + 1)`` around positions with ``xs[i] >= threshold``; bands closer than
+    the radius are merged (``blot.py:37-76``)."""
+    peaks, cur_peak = [], None
+    for idx, x in enumerate(xs):
+        radius = rs[idx] if isinstance(rs, (list, tuple, np.ndarray)) else rs
+        if x < threshold:
+            continue
+        peak_l, peak_r = max(0, idx - 1), min(len(xs) - 1, idx + 1)
+        if cur_peak is None:
+            cur_peak = (peak_l, peak_r)
+            continue
+        if peak_l < cur_peak[1] + radius:
+            assert peak_r >= cur_peak[1]
+            cur_peak = (cur_peak[0], peak_r)
+        else:
+            peaks.append(cur_peak)
+            cur_peak = (peak_l, peak_r)
+    if cur_peak is not None:
+        peaks.append(cur_peak)
+    return [(int(l), int(r)) for (l, r) in peaks]
+
+
+def wall_to_wall_distance(len0, len1, diag):
+    return min(len0 - diag, len1) + min(diag, 0)
+
+
+def expected_overlap_len(len0, len1, diag, gap_prob):
+    L = wall_to_wall_distance(len0, len1, diag)
+    expected_len = (2. / (2 - gap_prob)) * L
+    assert expected_len >= 0
+    return int(np.ceil(expected_len))
+
+
+def band_radius(expected_len, gap_prob, sensitivity):
+    assert 0 < gap_prob < 1 and 0 < sensitivity < 1
+    epsilon = 1. - sensitivity
+    C = erfcinv(epsilon) * np.sqrt(2 * gap_prob)
+    radius = C * np.sqrt(expected_len)
+    return max(1, int(np.ceil(radius)))
+
+
+def band_radii(expected_lens, gap_prob, sensitivity):
+    assert 0 < gap_prob < 1 and 0 < sensitivity < 1
+    epsilon = 1. - sensitivity
+    C = erfcinv(epsilon) * np.sqrt(2 * gap_prob)
+    K = np.asarray(list(expected_lens), dtype=np.float64)
+    return np.maximum(1, np.ceil(C * np.sqrt(K)).astype(np.int64))
+
+
+def H0_moments(alphabet_len, wordlen, area):
+    p_H0 = 1. / alphabet_len
+    pw_H0 = p_H0 ** wordlen
+    mu_H0 = area * pw_H0
+    sd_H0 = np.sqrt(area * ((1 - pw_H0) * (pw_H0 + 2 * p_H0 * pw_H0 / (1 - p_H0)) - 2 * wordlen * pw_H0 ** 2))
+    return mu_H0, sd_H0
+
+
+def H1_moments(alphabet_len, wordlen, area, seglen, p_match):
+    mu_H0, sd_H0 = H0_moments(alphabet_len, wordlen, area)
+    p_H1 = p_match
+    if p_H1 == 1.:
+        p_H1 = 1 - np.finfo(float).eps
+    pw_H1 = p_H1 ** wordlen
+    mu_H1 = mu_H0 + seglen * pw_H1
+    sd_H1 = np.sqrt(sd_H0 ** 2 + seglen * ((1 - pw_H1) * (pw_H1 + 2 * p_H1 * pw_H1 / (1 - p_H1)) - 2 * wordlen * pw_H1 ** 2))
+    return mu_H1, sd_H1
+
+
+class WordBlotOverlap(SeedIndex):
+    """Overlap (suffix-prefix) similarity detection between two sequences (``blot.py:228-236, 490-579``).
+
+    Keyword Args:
+        g_max (float): upper bound for indel probabilities.  sensitivity (float): desired band sensitivity.
+        wordlen, alphabet, mask, device: as :class:`biseqt_amd.seeds.SeedIndex`.
+    """
+
+    def __init__(self, S, T, g_max=None, sensitivity=None, **kw):
+        assert 0 < g_max < 1 and 0 < sensitivity < 1
+        self.g_max = g_max
+        self.sensitivity = sensitivity
+        super(WordBlotOverlap, self).__init__(S, T, **kw)
+        assert not self.self_comp, 'overlap detection compares two different sequences'
+
+    def band_radius(self, K):
+        return band_radius(K, self.g_max, self.sensitivity)
+
+    def _tables(self):
+        """L(d) and r(d) for every diagonal d = -|T| .. |S| (index d + |T|), the reference's `_len` / `_rad`."""
+        lenS, lenT = len(self.S), len(self.T)
+        d = np.arange(-lenT, lenS + 1, dtype=np.int64)
+        wall = np.minimum(lenS - d, lenT) + np.minimum(d, 0)
+        L = np.ceil((2. / (2 - self.g_max)) * wall).astype(np.int64)
+        rad = band_radii(L, self.g_max, self.sensitivity)
+        return L, rad
+
+    def score_seeds(self):
+        """One dict per seed, in table order: ``seed`` (d, a), ``r`` band radius at its diagonal, ``L`` expected
+        overlap length, ``p`` estimated match probability (``blot.py:497-556``)."""
+        rows = self.rows()
+        if not len(rows):
+            return []
+        L_tab, r_tab = self._tables()
+        n = self._idx.band_neighbours(r_tab.astype(np.float64)).astype(np.int64)
+        lenT = len(self.T)
+        d = rows[:, 0].astype(np.int64)
+        L = L_tab[d + lenT]
+        rad = r_tab[d + lenT]
+        area = 2 * rad * L
+        word_p_null = (1. / len(self.alphabet)) ** self.wordlen
+        word_p = (n + 1 - area * word_p_null) / L
+        pos = word_p > 0                      # log(x <= 0) warns, which the reference answers with p = 0 (:541-545)
+        p = np.zeros(len(rows))
+        p[pos] = np.exp(np.log(word_p[pos]) / self.wordlen)
+        p = np.minimum(p, 1)
+        return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'r': np.float64(rad[k]), 'L': int(L[k]), 'p': p[k]}
+                for k in range(len(rows))]
+
+    def highest_scoring_overlap_band(self):
+        """The diagonal band with the highest estimated match probability: ``d_band``, ``p``, ``len``, ``score``
+        (z-score under H1), or None without seeds (``blot.py:558-579``)."""
+        scored = self.score_seeds()
+        if not scored:
+            return None
+        idx = max(range(len(scored)), key=lambda i: scored[i]['p'])
+        seed, rad = scored[idx]['seed'], scored[idx]['r']
+        p_hat, overlap_len = scored[idx]['p'], scored[idx]['L']
+        d_band = seed[0] - rad, seed[0] + rad
+        res = {'d_band': d_band, 'p': p_hat, 'len': overlap_len}
+        area = 2 * rad * overlap_len
+        mu_H1, sd_H1 = H1_moments(len(self.alphabet), self.wordlen, area, overlap_len, p_hat)
+        num_seeds = self.seed_count(d_band=d_band)
+        res['score'] = (num_seeds - mu_H1) / sd_H1
+        return res

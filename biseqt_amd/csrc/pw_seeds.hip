@@ -133,6 +133,29 @@ __global__ __launch_bounds__(256) void k_count(const int2* __restrict__ rows, in
   if ((threadIdx.x & 63u) == 0 && c) atomicAdd(out, c);
 }
 
+// ---- K6: neighbours on the scaled diagonal axis (blot.py:521-527) -------------------------------------------
+__global__ __launch_bounds__(256) void k_scale(const int2* __restrict__ rows, int64_t nrows, const double* __restrict__ radius,
+                                               int nT, double* __restrict__ x) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= nrows) return;
+  const int d = rows[o].x;
+  x[o] = (double)d / radius[d + nT];
+}
+// xs sorted ascending.  The two predicates are the KD-tree's own test fl(|x - x'|) <= 1, one side each; both are
+// monotone along xs (rounding is monotone), so a binary search on the predicate itself is exact.
+__global__ __launch_bounds__(256) void k_neigh(const double* __restrict__ x, const double* __restrict__ xs, int64_t nrows,
+                                               int32_t* __restrict__ counts) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= nrows) return;
+  const double v = x[o];
+  int64_t lo = 0, hi = nrows;                     // first index with v - xs[idx] <= 1
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (!(v - xs[mid] <= 1.0)) lo = mid + 1; else hi = mid; }
+  const int64_t first = lo;
+  lo = 0; hi = nrows;                             // first index with NOT (xs[idx] - v <= 1)
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (xs[mid] - v <= 1.0) lo = mid + 1; else hi = mid; }
+  counts[o] = (int32_t)(lo - first - 1);
+}
+
 __global__ void k_total(const uint64_t* __restrict__ off, const uint64_t* __restrict__ cnt, int64_t ns,
                         unsigned long long* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ns > 0 ? off[ns - 1] + cnt[ns - 1] : 0ull;
@@ -321,6 +344,35 @@ int64_t pw_seeds_kmers(const pw_seed_index* xc, int which, int64_t* out, int64_t
   if (e != hipSuccess) { set_err("D2H of the k-mers failed"); return -1; }
   for (int64_t i = 0; i < nk; i++) out[i] = h[(size_t)i] >= x->kinv ? -1 : (int64_t)h[(size_t)i];
   return nk;
+}
+
+int pw_seeds_band_neighbours(const pw_seed_index* xc, const double* radius, int64_t n_radius, int32_t* counts, int64_t cap) {
+  pw_seed_index* x = const_cast<pw_seed_index*>(xc);
+  if (!x || x->nrows < 0) { set_err("pw_seeds_band_neighbours before a successful pw_seeds_build"); return -1; }
+  if (x->self) { set_err("pw_seeds_band_neighbours is not defined for a self comparison"); return -1; }
+  if (n_radius != x->nS + x->nT + 1) { set_err("radius table must hold nS + nT + 1 entries (d = -nT .. nS)"); return -1; }
+  if (cap < x->nrows) { set_err("pw_seeds_band_neighbours: capacity too small"); return -1; }
+  for (int64_t i = 0; i < n_radius; i++) if (!(radius[i] > 0)) { set_err("band radii must be positive"); return -1; }
+  const int64_t n = x->nrows;
+  if (n == 0) return 0;
+  SD_CHECK(hipSetDevice(x->device));
+  DevBuf rad, xu, xs, cn;
+  int rc = -1;
+  do {
+    if (rad.ensure((size_t)n_radius * 8) != 0 || xu.ensure((size_t)n * 8) != 0 || xs.ensure((size_t)n * 8) != 0 || cn.ensure((size_t)n * 4) != 0) break;
+    if (hipMemcpy(rad.p, radius, (size_t)n_radius * 8, hipMemcpyHostToDevice) != hipSuccess) { set_err("H2D of the radius table failed"); break; }
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const int2*)x->rows.p, n,
+                       (const double*)rad.p, (int)x->nT, (double*)xu.p);
+    size_t tb = 0;
+    if (rocprim::radix_sort_keys(nullptr, tb, (const double*)xu.p, (double*)xs.p, (size_t)n, 0u, 64u, (hipStream_t) nullptr) != hipSuccess) { set_err("radix_sort_keys (size) failed"); break; }
+    if (x->tmp.ensure(tb) != 0) break;
+    if (rocprim::radix_sort_keys(x->tmp.p, tb, (const double*)xu.p, (double*)xs.p, (size_t)n, 0u, 64u, (hipStream_t) nullptr) != hipSuccess) { set_err("radix_sort_keys failed"); break; }
+    hipLaunchKernelGGL(k_neigh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const double*)xu.p, (const double*)xs.p, n, (int32_t*)cn.p);
+    if (hipMemcpy(counts, cn.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("D2H of the neighbour counts failed"); break; }
+    rc = 0;
+  } while (0);
+  rad.release(); xu.release(); xs.release(); cn.release();
+  return rc;
 }
 
 void pw_seeds_destroy(pw_seed_index* x) {

@@ -68,6 +68,15 @@ class _Index(object):
             raise RuntimeError('pw_seeds_count failed: ' + self.error())
         return n
 
+    def band_neighbours(self, radius):
+        """Per row: how many other rows lie within 1 on the axis d / radius(d) (radius: table over d = -nT .. nS)."""
+        n = self.lib.pw_seeds_num_rows(self.handle)
+        rad = np.ascontiguousarray(radius, np.float64)
+        out = np.zeros(max(n, 1), np.int32)
+        if self.lib.pw_seeds_band_neighbours(self.handle, rad.ctypes.data, rad.size, out.ctypes.data, n) != 0:
+            raise RuntimeError('pw_seeds_band_neighbours failed: ' + self.error())
+        return out[:n]
+
     def kmers(self, which):
         n = (self.nT if which else self.nS) - self.wordlen + 1
         out = np.zeros(max(n, 1), np.int64)

@@ -59,6 +59,14 @@ int64_t pw_seeds_count(const pw_seed_index* idx, int have_d, int32_t dmin, int32
  * (masked positions: -1); n - k + 1 entries.  Device work, synchronous. */
 int64_t pw_seeds_kmers(const pw_seed_index* idx, int which, int64_t* out, int64_t cap);
 
+/* Band selection support (biseqt/blot.py:497-531, WordBlotOverlap.score_seeds): for every row, in table order,
+ * the number of OTHER rows whose scaled diagonal d' / radius(d') is within 1 of its own d / radius(d) -- what
+ * cKDTree.query_ball_tree(r = 1, p = inf) over the points (d / r(d),) returns, minus the point itself.
+ * radius[d + nT] is the band radius of diagonal d for d = -nT .. nS (n_radius = nS + nT + 1 doubles: the
+ * reference divides by the float np.ceil(...) returns).  Not defined for self comparisons (-1). */
+int pw_seeds_band_neighbours(const pw_seed_index* idx, const double* radius, int64_t n_radius, int32_t* counts,
+                             int64_t cap);
+
 double pw_seeds_build_ms(const pw_seed_index* idx);           /* device time of the last build (HIP events) */
 int64_t pw_seeds_algorithmic_bytes(const pw_seed_index* idx); /* see DESIGN.md: bytes the build must move */
 void pw_seeds_destroy(pw_seed_index* idx);

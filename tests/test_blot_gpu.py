@@ -1,0 +1,79 @@
+"""GPU band selection (biseqt_amd.blot.WordBlotOverlap over include/pw_seeds.h) against the oracle, which runs the
+reference's own neighbour search (scipy cKDTree) on the CPU; and the reference's overlap-detection test
+(tests/test_blot.py:160-197) end to end: seeds -> band -> banded overlap alignment on the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(A, arr):
+    from biseqt_amd.sequence import Sequence
+    return Sequence(A, tuple(int(c) for c in arr))
+
+
+def test_closed_forms_match_oracle():
+    from biseqt_amd import blot as B
+    from oracle import blot_oracle as BO
+    assert B.band_radius(2000, .2, .99) == 52 and B.expected_overlap_len(5000, 5000, 1000, .2) == 4445
+    for g, s in ((.1, .99), (.2, .999), (.05, .9)):
+        lens = [B.expected_overlap_len(700, 900, d, g) for d in range(-900, 701)]
+        assert lens == [BO.expected_overlap_len(700, 900, d, g) for d in range(-900, 701)]
+        assert B.band_radii(lens, g, s).tolist() == BO.band_radii(lens, g, s).tolist()
+        assert all(B.band_radius(K, g, s) == BO.band_radius(K, g, s) for K in lens[::37])
+    assert B.find_peaks([0, 1, 2, 3, 100, 5, 6, 7, 100, 9, 10, 11, 12, 13], 3, 100) == [(3, 9)]
+    for args in ((4, 8, 1234.), (4, 15, 1e6), (20, 3, 50.)):
+        assert B.H0_moments(*args) == BO.H0_moments(*args)
+        assert B.H1_moments(*args, 500, .9) == BO.H1_moments(*args, 500, .9)
+
+
+@pytest.mark.parametrize('wordlen,K,n', [(8, 500, 2000), (8, 1000, 2000), (15, 500, 2000), (6, 300, 1200)])
+def test_score_seeds_and_best_band_vs_oracle(wordlen, K, n):
+    from biseqt_amd import synth
+    from biseqt_amd.blot import WordBlotOverlap
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO
+    A = Alphabet('ACGT')
+    rng = synth.rng_for(wordlen * 1000 + K)
+    overlap = synth.rand_seqs(rng, 1, K)[0]
+    S = np.concatenate([synth.rand_seqs(rng, 1, n - K)[0], overlap])
+    T = np.concatenate([synth.mutate(rng, overlap, .05, .05, .05), synth.rand_seqs(rng, 1, n - K)[0]])
+    for (s, t) in ((S, T), (T, S), (S[:300], T[:40])):
+        wb = WordBlotOverlap(_mk(A, s), _mk(A, t), g_max=.2, sensitivity=.99, alphabet=A, wordlen=wordlen)
+        got = wb.score_seeds()
+        exp = BO.score_seeds(s.tolist(), t.tolist(), wordlen, 4, .2, .99)
+        assert len(got) == len(exp)
+        for g, e in zip(got, exp):
+            assert g['seed'] == e['seed'] and g['r'] == e['r'] and g['L'] == e['L'] and g['p'] == e['p'], (g, e)
+        rec = wb.highest_scoring_overlap_band()
+        ref = BO.highest_scoring_overlap_band(s.tolist(), t.tolist(), wordlen, 4, .2, .99)
+        assert (rec is None) == (ref is None)
+        if rec is not None:
+            assert rec['d_band'] == ref['d_band'] and rec['p'] == ref['p'] and rec['len'] == ref['len']
+            assert rec['score'] == ref['score']
+        wb.close()
+
+
+def test_overlap_detection_then_banded_alignment():
+    """tests/test_blot.py:160-197 restated, then the band goes to the banded overlap aligner."""
+    from biseqt_amd import synth
+    from biseqt_amd.blot import WordBlotOverlap
+    from biseqt_amd.pw import Aligner, BANDED_MODE, B_OVERLAP
+    from biseqt_amd.sequence import Alphabet
+    A = Alphabet('ACGT')
+    gap, subst, n, K = .05, .05, 5000, 1000
+    rng = synth.rng_for(77)
+    overlap = synth.rand_seqs(rng, 1, K)[0]
+    S = _mk(A, np.concatenate([synth.rand_seqs(rng, 1, n - K)[0], overlap]))
+    T = _mk(A, np.concatenate([synth.mutate(rng, overlap, subst, gap, gap), synth.rand_seqs(rng, 1, n - K)[0]]))
+    wb = WordBlotOverlap(S, T, g_max=.2, sensitivity=.99, alphabet=A, wordlen=8)
+    rec = wb.highest_scoring_overlap_band()
+    d_min, d_max = rec['d_band']
+    assert d_min * .9 < n - K < 1.1 * d_max and rec['p'] > .9 * (1 - gap) * (1 - subst)
+    band = (max(int(d_min), -len(T)), min(int(d_max), len(S)))
+    with Aligner(S, T, alnmode=BANDED_MODE, alntype=B_OVERLAP, diag_range=band,
+                 match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as aligner:
+        score = aligner.solve()
+        aln = aligner.traceback()
+    assert score is not None and score > 0.5 * K
+    assert abs(aln.origin_start - (n - K)) < 30 and aln.mutant_start == 0
