@@ -3,8 +3,9 @@
 What is here: the closed-form geometry and statistics of Word-Blot (``wall_to_wall_distance`` :78-89,
 ``expected_overlap_len`` :92-112, ``band_radius`` / ``band_radii`` :116-160, ``H0_moments`` / ``H1_moments``
 :163-218, ``find_peaks`` :37-76) -- scalar arithmetic, evaluated on the host exactly as the reference writes it --
-and ``WordBlotOverlap`` (:490-579), whose heavy part (for every seed, the number of seeds in its diagonal
-neighbourhood, a KD-tree ball query in the reference) runs on the GPU (kernel K6 of pw_seeds.hip).
+``WordBlot`` (:228-490: ``score_seeds``, ``similar_segments``) and ``WordBlotOverlap`` (:490-579), whose heavy
+parts -- for every seed the seeds in its neighbourhood (KD-tree ball queries in the reference) and the growth of
+neighbouring seeds into segments (a depth-first search there) -- run on the GPU (kernels K6, K7 of pw_seeds.hip).
 ``highest_scoring_overlap_band()`` returns the ``d_band`` that the banded overlap aligner
 (``Aligner(..., alnmode=BANDED_MODE, alntype=B_OVERLAP, diag_range=d_band)``) is given.
 """
@@ -83,8 +84,8 @@ def H1_moments(alphabet_len, wordlen, area, seglen, p_match):
     return mu_H1, sd_H1
 
 
-class WordBlotOverlap(SeedIndex):
-    """Overlap (suffix-prefix) similarity detection between two sequences (``blot.py:228-236, 490-579``).
+class WordBlot(SeedIndex):
+    """A similarity finder based on m-dependent CLT statistics (``blot.py:228-490``).
 
     Keyword Args:
         g_max (float): upper bound for indel probabilities.  sensitivity (float): desired band sensitivity.
@@ -95,11 +96,129 @@ class WordBlotOverlap(SeedIndex):
         assert 0 < g_max < 1 and 0 < sensitivity < 1
         self.g_max = g_max
         self.sensitivity = sensitivity
-        super(WordBlotOverlap, self).__init__(S, T, **kw)
-        assert not self.self_comp, 'overlap detection compares two different sequences'
+        super(WordBlot, self).__init__(S, T, **kw)
+        self._graph_key = None
+
+    def score_num_seeds(self, **kw):
+        """z-scores of an observed number of seeds in a region against H0 and H1 (``blot.py:238-271``)."""
+        num_seeds, area = kw['num_seeds'], kw['area']
+        if area == 0:
+            return float('-inf'), float('-inf')
+        mu_H0, sd_H0 = H0_moments(len(self.alphabet), self.wordlen, area)
+        mu_H1, sd_H1 = H1_moments(len(self.alphabet), self.wordlen, area, kw['seglen'], kw['p_match'])
+        return (num_seeds - mu_H0) / sd_H0, (num_seeds - mu_H1) / sd_H1
 
     def band_radius(self, K):
         return band_radius(K, self.g_max, self.sensitivity)
+
+    def segment_dims(self, d_band=None, a_band=None):
+        """Edit path length and area of a diagonal / antidiagonal segment (``blot.py:283-303``; the reference
+        divides with python 2's integer ``/``)."""
+        a_min, a_max = a_band
+        d_min, d_max = d_band
+        K = (a_max - a_min) // 2
+        A = (d_max - d_min) * K
+        return K, A
+
+    def estimate_match_probability(self, num_seeds, d_band=None, a_band=None):
+        """``p = ((n - A p0^w) / K)^(1/w)``, 0 where the logarithm is undefined (``blot.py:305-341``)."""
+        K, area = self.segment_dims(d_band=d_band, a_band=a_band)
+        word_p_null = (1. / len(self.alphabet)) ** self.wordlen
+        word_p = (num_seeds - area * word_p_null) / K
+        if not word_p > 0:
+            match_p = 0
+        else:
+            match_p = np.exp(np.log(word_p) / self.wordlen)
+        return min(match_p, 1)
+
+    def _graph(self, d_radius, a_radius):
+        """The neighbourhood graph of ``find_all_neighbors`` (``blot.py:343-374``), built on the GPU once per
+        (d_radius, a_radius)."""
+        assert not self.self_comp, 'local similarity search between a sequence and itself is not supported'
+        key = (d_radius, a_radius)
+        if self._graph_key != key:
+            self._idx.graph_build(1. * a_radius / d_radius, a_radius)
+            self._graph_key = key
+
+    def _seed_ps(self, K):
+        d_radius = int(np.ceil(self.band_radius(K)))
+        a_radius = K
+        self._graph(d_radius, a_radius)
+        n = self._idx.graph_counts().astype(np.int64)
+        # every seed's segment has the same dimensions: K' = a_radius, A = 2 d_radius a_radius
+        Kp, area = self.segment_dims(d_band=(-d_radius, d_radius), a_band=(-a_radius, a_radius))
+        word_p_null = (1. / len(self.alphabet)) ** self.wordlen
+        word_p = (n + 1 - area * word_p_null) / Kp
+        p = np.zeros(len(n))
+        pos = word_p > 0
+        p[pos] = np.exp(np.log(word_p[pos]) / self.wordlen)
+        return np.minimum(p, 1), d_radius, a_radius
+
+    def score_seeds(self, K):
+        """One dict per seed, in table order: ``seed`` (d, a), ``neighs`` (indices of the seeds in its
+        neighbourhood), ``p`` estimated match probability of a segment centred there (``blot.py:376-408``)."""
+        rows = self.rows()
+        if not len(rows):
+            return []
+        p, _, _ = self._seed_ps(K)
+        off, adj = self._idx.graph_fetch()
+        return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'neighs': adj[off[k]:off[k + 1]].tolist(), 'p': p[k]}
+                for k in range(len(rows))]
+
+    def similar_segments(self, K_min, p_min, at_least_one=False):
+        """All maximal local similarities of a minimum length and match probability (``blot.py:410-490``): seeds
+        with ``p >= p_min`` are grown into connected groups (the reference's depth-first search finds the
+        connected components of the neighbourhood graph; they are computed on the GPU), each group's bounding
+        segment is clamped to the table, scored and yielded in the order of its first seed."""
+        rows = self.rows()
+        if not len(rows):
+            assert not at_least_one, 'no seeds found while at_least_one=True'
+            return
+        p, d_radius, a_radius = self._seed_ps(K_min)
+        avail = p >= p_min
+        if not avail.any() and at_least_one:
+            avail[int(np.argmax(p))] = True
+        if not avail.any():
+            return
+        labels = self._idx.graph_components(avail)
+        idx = np.flatnonzero(labels >= 0)
+        order = idx[np.argsort(labels[idx], kind='stable')]
+        lab = labels[order]
+        starts = np.flatnonzero(np.r_[True, lab[1:] != lab[:-1]])
+        d, a = rows[order, 0].astype(np.int64), rows[order, 1].astype(np.int64)
+        lenS, lenT = len(self.S), len(self.T)
+        d_lo = np.minimum.reduceat(d, starts) - d_radius
+        d_hi = np.maximum.reduceat(d, starts) + d_radius
+        a_lo = np.minimum.reduceat(a, starts) - a_radius
+        a_hi = np.maximum.reduceat(a, starts) + a_radius
+        psum = np.add.reduceat(p[order], starts)
+        cnt = np.diff(np.r_[starts, len(order)])
+        for s in range(len(starts)):
+            first = int(lab[starts[s]])              # the seed the search starts from is counted twice (:449,455)
+            d_min = min(lenS, max(int(d_lo[s]), -lenT))
+            d_max = min(lenS, max(int(d_hi[s]), -lenT))
+            a_min = max(int(a_lo[s]), 0)
+            a_max = min(int(a_hi[s]), lenS + lenT)
+            seg = (d_min, d_max), (a_min, a_max)
+            p_hat = (psum[s] + p[first]) / (cnt[s] + 1)
+            res = {'segment': seg, 'p': p_hat}
+            n = self.seed_count(d_band=seg[0], a_band=seg[1])
+            K_hat, area_hat = self.segment_dims(d_band=seg[0], a_band=seg[1])
+            res['scores'] = self.score_num_seeds(num_seeds=n, area=area_hat, seglen=K_hat, p_match=p_hat)
+            yield res
+
+
+class WordBlotOverlap(WordBlot):
+    """Overlap (suffix-prefix) similarity detection between two sequences (``blot.py:228-236, 490-579``).
+
+    Keyword Args:
+        g_max (float): upper bound for indel probabilities.  sensitivity (float): desired band sensitivity.
+        wordlen, alphabet, mask, device: as :class:`biseqt_amd.seeds.SeedIndex`.
+    """
+
+    def __init__(self, S, T, g_max=None, sensitivity=None, **kw):
+        super(WordBlotOverlap, self).__init__(S, T, g_max=g_max, sensitivity=sensitivity, **kw)
+        assert not self.self_comp, 'overlap detection compares two different sequences'
 
     def _tables(self):
         """L(d) and r(d) for every diagonal d = -|T| .. |S| (index d + |T|), the reference's `_len` / `_rad`."""

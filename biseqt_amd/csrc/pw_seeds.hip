@@ -156,6 +156,84 @@ __global__ __launch_bounds__(256) void k_neigh(const double* __restrict__ x, con
   counts[o] = (int32_t)(lo - first - 1);
 }
 
+// ---- K7: the neighbourhood graph of the seeds (blot.py:343-374) and its connected components (:452-468) ----------
+__global__ __launch_bounds__(256) void k_graph_keys(const int2* __restrict__ rows, int64_t n, int nT, uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const int2 r = rows[o];
+  keys[o] = ((uint64_t)(uint32_t)(r.x + nT) << 32) | (uint32_t)r.y;
+  vals[o] = (uint32_t)o;
+}
+__global__ __launch_bounds__(256) void k_graph_dstart(const uint64_t* __restrict__ keys, int64_t n, int64_t nd, uint32_t* __restrict__ dstart) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q > nd) return;
+  dstart[q] = (uint32_t)lower_bound_u64(keys, n, (uint64_t)q << 32);
+}
+// One thread per seed in (d, a) order.  For every diagonal d' that passes the KD-tree's test on the scaled axis,
+// fl(|fl(d c) - fl(d' c)|) <= R, the seeds with |a - a'| <= R form one contiguous piece of that diagonal's run.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_graph_scan(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ order, int64_t n,
+                                                    const uint32_t* __restrict__ dstart, int nd, int nT, double c, double R, int win,
+                                                    uint32_t* __restrict__ cnt, const uint64_t* __restrict__ off,
+                                                    uint32_t* __restrict__ adj) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n) return;
+  const uint64_t key = keys[s];
+  const uint32_t o = order[s];
+  const int q = (int)(key >> 32);
+  const int64_t a = (int64_t)(uint32_t)key;
+  const double X = (double)(q - nT) * c;
+  const int64_t ra = (int64_t)floor(R);           // |a - a'| <= R for integers
+  uint64_t w = FILL ? off[o] : 0;
+  uint32_t total = 0;
+  const int q0 = q - win < 0 ? 0 : q - win, q1 = q + win > nd - 1 ? nd - 1 : q + win;
+  for (int qq = q0; qq <= q1; qq++) {
+    const double Xp = (double)(qq - nT) * c;
+    if (!(fabs(X - Xp) <= R)) continue;
+    const int64_t b = dstart[qq], e = dstart[qq + 1];
+    if (b == e) continue;
+    const int64_t alo = a - ra < 0 ? 0 : a - ra, ahi = a + ra;
+    const uint64_t klo = ((uint64_t)(uint32_t)qq << 32) | (uint64_t)alo;
+    const uint64_t khi = ((uint64_t)(uint32_t)qq << 32) | (uint64_t)(ahi > 0xffffffffll ? 0xffffffffll : ahi);
+    const int64_t lo = b + lower_bound_u64(keys + b, e - b, klo);
+    const int64_t hi = b + upper_bound_u64(keys + b, e - b, khi);
+    if (!FILL) total += (uint32_t)(hi - lo);
+    else for (int64_t t = lo; t < hi; t++) { const uint32_t v = order[t]; if (v != o) adj[w++] = v; }
+  }
+  if (!FILL) cnt[o] = total - 1;                  // its own entry is removed (blot.py:371-372)
+}
+__global__ __launch_bounds__(256) void k_widen(const uint32_t* __restrict__ in, int64_t n, uint64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__device__ __forceinline__ int cc_root(const int* __restrict__ parent, int v) {
+  int p = parent[v];
+  while (p != v) { v = p; p = parent[v]; }
+  return v;
+}
+__global__ __launch_bounds__(256) void k_cc_init(const uint8_t* __restrict__ avail, int64_t n, int* __restrict__ parent) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) parent[i] = avail[i] ? (int)i : -1;
+}
+__global__ __launch_bounds__(256) void k_cc_hook(const uint64_t* __restrict__ off, const uint32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ adj, int64_t n, int* __restrict__ parent,
+                                                 int* __restrict__ changed) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= n || parent[u] < 0) return;
+  const uint64_t b = off[u], e = b + cnt[u];
+  for (uint64_t t = b; t < e; t++) {
+    const int v = (int)adj[t];
+    if (parent[v] < 0) continue;
+    const int ru = cc_root(parent, (int)u), rv = cc_root(parent, v);
+    if (ru != rv) { atomicMin(&parent[ru > rv ? ru : rv], ru > rv ? rv : ru); *changed = 1; }
+  }
+}
+__global__ __launch_bounds__(256) void k_cc_compress(int64_t n, int* __restrict__ parent) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && parent[i] >= 0) parent[i] = cc_root(parent, (int)i);
+}
+
 __global__ void k_total(const uint64_t* __restrict__ off, const uint64_t* __restrict__ cnt, int64_t ns,
                         unsigned long long* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = ns > 0 ? off[ns - 1] + cnt[ns - 1] : 0ull;
@@ -182,6 +260,8 @@ struct pw_seed_index {
   uint64_t kinv = 0;
   MaskSets ms;
   DevBuf dS, dT, keys_in, keys_s, keys_t, pos_in, pos_s, pos_t, lo, cnt, off, rows, tmp, scalar;
+  DevBuf g_keys, g_order, g_dstart, g_cnt, g_off, g_adj;     // neighbourhood graph (K7)
+  int64_t g_edges = -1;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float ms_build = 0.f;
 };
@@ -248,7 +328,7 @@ int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   SD_CHECK(hipSetDevice(x->device));
   if (max_rows <= 0) max_rows = (1ll << 31) - 1;
-  x->nrows = -1;
+  x->nrows = -1; x->g_edges = -1;
   SD_CHECK(hipEventRecord(x->ev0, st));
   if (encode_sort(x, (const uint8_t*)x->dS.p, x->nS, x->nkS, x->keys_s, x->pos_s, st) != 0) return -1;
   if (!x->self && encode_sort(x, (const uint8_t*)x->dT.p, x->nT, x->nkT, x->keys_t, x->pos_t, st) != 0) return -1;
@@ -375,11 +455,112 @@ int pw_seeds_band_neighbours(const pw_seed_index* xc, const double* radius, int6
   return rc;
 }
 
+int64_t pw_seeds_graph_build(pw_seed_index* x, double d_coeff, double radius) {
+  if (!x || x->nrows < 0) { set_err("pw_seeds_graph_build before a successful pw_seeds_build"); return -1; }
+  if (x->self) { set_err("the neighbourhood graph is not defined for a self comparison"); return -1; }
+  if (!(d_coeff > 0) || !(radius >= 0)) { set_err("d_coeff must be positive and radius non-negative"); return -1; }
+  x->g_edges = -1;
+  const int64_t n = x->nrows;
+  if (n == 0) { x->g_edges = 0; return 0; }
+  SD_CHECK(hipSetDevice(x->device));
+  const int64_t nd = x->nS + x->nT + 1;
+  const double wd = floor(radius / d_coeff) + 2;
+  const int win = wd > (double)nd ? (int)nd : (int)wd;
+  DevBuf kin, vin;
+  int64_t rc = -1;
+  do {
+    if (kin.ensure((size_t)n * 8) != 0 || vin.ensure((size_t)n * 4) != 0) break;
+    if (x->g_keys.ensure((size_t)n * 8) != 0 || x->g_order.ensure((size_t)n * 4) != 0 || x->g_dstart.ensure((size_t)(nd + 1) * 4) != 0 ||
+        x->g_cnt.ensure((size_t)n * 4) != 0 || x->g_off.ensure((size_t)(n + 1) * 8) != 0) break;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_graph_keys, grid, blk, 0, nullptr, (const int2*)x->rows.p, n, (int)x->nT, (uint64_t*)kin.p, (uint32_t*)vin.p);
+    int dbits = 1; while (((uint64_t)nd >> dbits) != 0) dbits++;
+    size_t tb = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)kin.p, (uint64_t*)x->g_keys.p, (const uint32_t*)vin.p, (uint32_t*)x->g_order.p,
+                                  (size_t)n, 0u, (unsigned)(32 + dbits), (hipStream_t) nullptr) != hipSuccess) { set_err("radix_sort_pairs (size) failed"); break; }
+    if (x->tmp.ensure(tb) != 0) break;
+    if (rocprim::radix_sort_pairs(x->tmp.p, tb, (const uint64_t*)kin.p, (uint64_t*)x->g_keys.p, (const uint32_t*)vin.p, (uint32_t*)x->g_order.p,
+                                  (size_t)n, 0u, (unsigned)(32 + dbits), (hipStream_t) nullptr) != hipSuccess) { set_err("radix_sort_pairs failed"); break; }
+    hipLaunchKernelGGL(k_graph_dstart, dim3((unsigned)((nd + 256) / 256)), blk, 0, nullptr, (const uint64_t*)x->g_keys.p, n, nd, (uint32_t*)x->g_dstart.p);
+    hipLaunchKernelGGL((k_graph_scan<false>), grid, blk, 0, nullptr, (const uint64_t*)x->g_keys.p, (const uint32_t*)x->g_order.p, n,
+                       (const uint32_t*)x->g_dstart.p, (int)nd, (int)x->nT, d_coeff, radius, win, (uint32_t*)x->g_cnt.p,
+                       (const uint64_t*)nullptr, (uint32_t*)nullptr);
+    // offsets = exclusive scan of the counts (64-bit)
+    uint64_t* wide = (uint64_t*)kin.p;            // reuse: n x 8 bytes
+    hipLaunchKernelGGL(k_widen, grid, blk, 0, nullptr, (const uint32_t*)x->g_cnt.p, n, wide);
+    tb = 0;
+    if (rocprim::exclusive_scan(nullptr, tb, (const uint64_t*)wide, (uint64_t*)x->g_off.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), (hipStream_t) nullptr) != hipSuccess) { set_err("exclusive_scan (size) failed"); break; }
+    if (x->tmp.ensure(tb) != 0) break;
+    if (rocprim::exclusive_scan(x->tmp.p, tb, (const uint64_t*)wide, (uint64_t*)x->g_off.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), (hipStream_t) nullptr) != hipSuccess) { set_err("exclusive_scan failed"); break; }
+    hipLaunchKernelGGL(k_total, dim3(1), dim3(64), 0, nullptr, (const uint64_t*)x->g_off.p, (const uint64_t*)wide, n, (unsigned long long*)x->scalar.p);
+    unsigned long long total = 0;
+    if (hipMemcpy(&total, x->scalar.p, 8, hipMemcpyDeviceToHost) != hipSuccess) { set_err("D2H of the edge count failed"); break; }
+    if (total >= (1ull << 32)) { set_err("the neighbourhood graph has more than 2^32 edges: use a smaller radius"); break; }
+    if (hipMemcpy((uint64_t*)x->g_off.p + n, &total, 8, hipMemcpyHostToDevice) != hipSuccess) { set_err("H2D failed"); break; }
+    if (x->g_adj.ensure((size_t)std::max<unsigned long long>(total, 1) * 4) != 0) break;
+    if (total) hipLaunchKernelGGL((k_graph_scan<true>), grid, blk, 0, nullptr, (const uint64_t*)x->g_keys.p, (const uint32_t*)x->g_order.p, n,
+                                  (const uint32_t*)x->g_dstart.p, (int)nd, (int)x->nT, d_coeff, radius, win, (uint32_t*)nullptr,
+                                  (const uint64_t*)x->g_off.p, (uint32_t*)x->g_adj.p);
+    if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) { set_err("the graph kernels failed"); break; }
+    rc = (int64_t)total;
+  } while (0);
+  kin.release(); vin.release();
+  x->g_edges = rc;
+  return rc;
+}
+
+int pw_seeds_graph_counts(const pw_seed_index* x, int32_t* counts, int64_t cap) {
+  if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_counts before a successful pw_seeds_graph_build"); return -1; }
+  if (cap < x->nrows) { set_err("pw_seeds_graph_counts: capacity too small"); return -1; }
+  SD_CHECK(hipSetDevice(x->device));
+  if (x->nrows) SD_CHECK(hipMemcpy(counts, x->g_cnt.p, (size_t)x->nrows * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pw_seeds_graph_fetch(const pw_seed_index* x, int64_t* offsets, int32_t* neighbours) {
+  if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_fetch before a successful pw_seeds_graph_build"); return -1; }
+  SD_CHECK(hipSetDevice(x->device));
+  if (x->nrows == 0) { offsets[0] = 0; return 0; }
+  SD_CHECK(hipMemcpy(offsets, x->g_off.p, (size_t)(x->nrows + 1) * 8, hipMemcpyDeviceToHost));
+  if (x->g_edges) SD_CHECK(hipMemcpy(neighbours, x->g_adj.p, (size_t)x->g_edges * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pw_seeds_graph_components(const pw_seed_index* x, const uint8_t* avail, int32_t* labels) {
+  if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_components before a successful pw_seeds_graph_build"); return -1; }
+  const int64_t n = x->nrows;
+  if (n == 0) return 0;
+  SD_CHECK(hipSetDevice(x->device));
+  DevBuf av, par, flag;
+  int rc = -1;
+  do {
+    if (av.ensure((size_t)n) != 0 || par.ensure((size_t)n * 4) != 0 || flag.ensure(16) != 0) break;
+    if (hipMemcpy(av.p, avail, (size_t)n, hipMemcpyHostToDevice) != hipSuccess) { set_err("H2D of avail failed"); break; }
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    hipLaunchKernelGGL(k_cc_init, grid, blk, 0, nullptr, (const uint8_t*)av.p, n, (int*)par.p);
+    bool ok = true;
+    for (int it = 0; it < 10000; it++) {          // every round at least halves the number of roots still to merge
+      if (hipMemsetAsync(flag.p, 0, 4, nullptr) != hipSuccess) { ok = false; break; }
+      hipLaunchKernelGGL(k_cc_hook, grid, blk, 0, nullptr, (const uint64_t*)x->g_off.p, (const uint32_t*)x->g_cnt.p,
+                         (const uint32_t*)x->g_adj.p, n, (int*)par.p, (int*)flag.p);
+      hipLaunchKernelGGL(k_cc_compress, grid, blk, 0, nullptr, n, (int*)par.p);
+      int changed = 0;
+      if (hipMemcpy(&changed, flag.p, 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+      if (!changed) break;
+    }
+    if (!ok) { set_err("the component kernels failed"); break; }
+    if (hipMemcpy(labels, par.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) { set_err("D2H of the labels failed"); break; }
+    rc = 0;
+  } while (0);
+  av.release(); par.release(); flag.release();
+  return rc;
+}
+
 void pw_seeds_destroy(pw_seed_index* x) {
   if (!x) return;
   (void)hipSetDevice(x->device);
   DevBuf* bufs[] = {&x->dS, &x->dT, &x->keys_in, &x->keys_s, &x->keys_t, &x->pos_in, &x->pos_s, &x->pos_t, &x->lo, &x->cnt,
-                    &x->off, &x->rows, &x->tmp, &x->scalar};
+                    &x->off, &x->rows, &x->tmp, &x->scalar, &x->g_keys, &x->g_order, &x->g_dstart, &x->g_cnt, &x->g_off, &x->g_adj};
   for (DevBuf* b : bufs) b->release();
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);

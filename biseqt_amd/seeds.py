@@ -77,6 +77,39 @@ class _Index(object):
             raise RuntimeError('pw_seeds_band_neighbours failed: ' + self.error())
         return out[:n]
 
+    def graph_build(self, d_coeff, radius):
+        """Neighbourhood graph of the rows: max(|d - d'| * d_coeff, |a - a'|) <= radius.  Returns the edge count."""
+        e = self.lib.pw_seeds_graph_build(self.handle, float(d_coeff), float(radius))
+        if e < 0:
+            raise RuntimeError('pw_seeds_graph_build failed: ' + self.error())
+        self._edges = e
+        return e
+
+    def graph_counts(self):
+        n = self.lib.pw_seeds_num_rows(self.handle)
+        out = np.zeros(max(n, 1), np.int32)
+        if self.lib.pw_seeds_graph_counts(self.handle, out.ctypes.data, n) != 0:
+            raise RuntimeError('pw_seeds_graph_counts failed: ' + self.error())
+        return out[:n]
+
+    def graph_fetch(self):
+        """CSR adjacency: (offsets[n + 1], neighbours[edges])."""
+        n = self.lib.pw_seeds_num_rows(self.handle)
+        off = np.zeros(n + 1, np.int64)
+        adj = np.zeros(max(self._edges, 1), np.int32)
+        if self.lib.pw_seeds_graph_fetch(self.handle, off.ctypes.data, adj.ctypes.data) != 0:
+            raise RuntimeError('pw_seeds_graph_fetch failed: ' + self.error())
+        return off, adj[:self._edges]
+
+    def graph_components(self, avail):
+        n = self.lib.pw_seeds_num_rows(self.handle)
+        av = np.ascontiguousarray(avail, np.uint8)
+        assert av.size == n
+        out = np.full(max(n, 1), -1, np.int32)
+        if self.lib.pw_seeds_graph_components(self.handle, av.ctypes.data, out.ctypes.data) != 0:
+            raise RuntimeError('pw_seeds_graph_components failed: ' + self.error())
+        return out[:n]
+
     def kmers(self, which):
         n = (self.nT if which else self.nS) - self.wordlen + 1
         out = np.zeros(max(n, 1), np.int64)

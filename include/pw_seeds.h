@@ -67,6 +67,22 @@ int64_t pw_seeds_kmers(const pw_seed_index* idx, int which, int64_t* out, int64_
 int pw_seeds_band_neighbours(const pw_seed_index* idx, const double* radius, int64_t n_radius, int32_t* counts,
                              int64_t cap);
 
+/* Local-similarity support (biseqt/blot.py:343-490, WordBlot.find_all_neighbors / score_seeds /
+ * similar_segments).  pw_seeds_graph_build links every pair of rows with
+ *     max(|d * d_coeff - d' * d_coeff|, |a - a'|) <= radius
+ * -- cKDTree.query_ball_tree(radius, p = inf) over the points (d * d_coeff, a), each row's own entry removed --
+ * and keeps the adjacency in HBM as CSR.  Returns the number of directed edges (every pair counts twice), or -1.
+ * Not defined for self comparisons. */
+int64_t pw_seeds_graph_build(pw_seed_index* idx, double d_coeff, double radius);
+int pw_seeds_graph_counts(const pw_seed_index* idx, int32_t* counts, int64_t cap);          /* neighbours per row */
+/* offsets: num_rows + 1 entries; neighbours: pw_seeds_graph_build's return value entries (row indices, the order
+ * inside a row's list is unspecified -- it is in the reference as well). */
+int pw_seeds_graph_fetch(const pw_seed_index* idx, int64_t* offsets, int32_t* neighbours);
+/* Connected components of the graph restricted to the rows with avail[row] != 0 (the depth-first growth of
+ * similar_segments, blot.py:452-468, finds exactly these): labels[row] = smallest row index of its component,
+ * -1 for rows that are not available. */
+int pw_seeds_graph_components(const pw_seed_index* idx, const uint8_t* avail, int32_t* labels);
+
 double pw_seeds_build_ms(const pw_seed_index* idx);           /* device time of the last build (HIP events) */
 int64_t pw_seeds_algorithmic_bytes(const pw_seed_index* idx); /* see DESIGN.md: bytes the build must move */
 void pw_seeds_destroy(pw_seed_index* idx);

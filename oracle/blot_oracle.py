@@ -142,3 +142,104 @@ def highest_scoring_overlap_band(S, T, wordlen, alphabet_len, g_max, sensitivity
     num_seeds = SO.seed_count(rows, d_band=d_band)
     res['score'] = (num_seeds - mu_H1) / sd_H1
     return res
+
+
+# ---- local similarities: WordBlot.score_seeds / similar_segments (blot.py:283-490) --------------------------------
+def segment_dims(d_band, a_band):                       # blot.py:283-303 (python-2 integer division)
+    a_min, a_max = a_band
+    d_min, d_max = d_band
+    K = (a_max - a_min) // 2
+    A = (d_max - d_min) * K
+    return K, A
+
+
+def estimate_match_probability(num_seeds, d_band, a_band, alphabet_len, wordlen):     # blot.py:305-341
+    K, area = segment_dims(d_band, a_band)
+    word_p_null = (1. / alphabet_len) ** wordlen
+    word_p = (num_seeds - area * word_p_null) / K
+    if not word_p > 0:
+        p = 0
+    else:
+        p = np.exp(np.log(word_p) / wordlen)
+    return min(p, 1)
+
+
+def score_num_seeds(num_seeds, area, seglen, p_match, alphabet_len, wordlen):         # blot.py:238-271
+    if area == 0:
+        return float('-inf'), float('-inf')
+    mu_H0, sd_H0 = H0_moments(alphabet_len, wordlen, area)
+    mu_H1, sd_H1 = H1_moments(alphabet_len, wordlen, area, seglen, p_match)
+    return (num_seeds - mu_H0) / sd_H0, (num_seeds - mu_H1) / sd_H1
+
+
+def find_all_neighbors(all_seeds, d_radius, a_radius):                                # blot.py:343-374
+    d_coeff = 1. * a_radius / d_radius
+    if not all_seeds:
+        return []
+    scaled = np.array([(d * d_coeff, a) for d, a in all_seeds])
+    tree = cKDTree(scaled)
+    neighs = tree.query_ball_tree(tree, a_radius, p=float('inf'))
+    for idx, _ in enumerate(neighs):
+        neighs[idx].remove(idx)
+    return list(zip(all_seeds, neighs))
+
+
+def score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K, mask=()):   # blot.py:376-408
+    rows, self_comp = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
+    ij = SO.seeds(rows, self_comp, exclude_trivial=True)
+    all_seeds = [SO.to_diagonal_coordinates(i, j) for i, j in ij]
+    d_radius = int(np.ceil(band_radius(K, g_max, sensitivity)))
+    a_radius = K
+    out = []
+    for (d, a), neighs in find_all_neighbors(all_seeds, d_radius, a_radius):
+        p = estimate_match_probability(len(neighs) + 1, (d - d_radius, d + d_radius), (a - a_radius, a + a_radius),
+                                       alphabet_len, wordlen)
+        out.append({'seed': (d, a), 'neighs': neighs, 'p': p})
+    return out
+
+
+def similar_segments(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, p_min, at_least_one=False, mask=()):
+    """blot.py:410-490, the depth-first growth included (the order of `ps_in_seg`, and with it the last bits of the
+    averaged p, follows the KD-tree's neighbour order)."""
+    rows, _ = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
+    d_radius = int(np.ceil(band_radius(K_min, g_max, sensitivity)))
+    a_radius = K_min
+    scored = score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, mask)
+    lenS, lenT = len(S), len(T)
+    avail = [rec['p'] >= p_min for rec in scored]
+    if not any(avail) and at_least_one:
+        assert len(scored)
+        avail[int(np.argmax([rec['p'] for rec in scored]))] = True
+    out = []
+    while True:
+        try:
+            seed_idx = avail.index(True)
+        except ValueError:
+            break
+        stack = [seed_idx]
+        avail[seed_idx] = False
+        ps = [scored[seed_idx]['p']]
+        seg = None
+        while stack:
+            idx = stack.pop()
+            ps.append(scored[idx]['p'])
+            d, a = scored[idx]['seed']
+            if seg is None:
+                seg = (d - d_radius, d + d_radius), (a - a_radius, a + a_radius)
+            else:
+                (d_min, d_max), (a_min, a_max) = seg
+                seg = (min(d - d_radius, d_min), max(d + d_radius, d_max)), (min(a - a_radius, a_min), max(a + a_radius, a_max))
+            for neigh in scored[idx]['neighs']:
+                if avail[neigh]:
+                    stack.append(neigh)
+                    avail[neigh] = False
+        (d_min, d_max), (a_min, a_max) = seg
+        d_min = min(lenS, max(d_min, -lenT)); d_max = min(lenS, max(d_max, -lenT))
+        a_min = max(a_min, 0); a_max = min(a_max, lenS + lenT)
+        seg = (d_min, d_max), (a_min, a_max)
+        p_hat = sum(ps) / len(ps)
+        n = SO.seed_count(rows, d_band=seg[0], a_band=seg[1])
+        K_hat, area_hat = segment_dims(seg[0], seg[1])
+        out.append({'segment': seg, 'p': p_hat,
+                    'scores': score_num_seeds(n, area_hat, K_hat, p_hat, alphabet_len, wordlen)})
+    return out

@@ -77,3 +77,47 @@ def test_overlap_detection_then_banded_alignment():
         aln = aligner.traceback()
     assert score is not None and score > 0.5 * K
     assert abs(aln.origin_start - (n - K)) < 30 and aln.mutant_start == 0
+
+
+@pytest.mark.parametrize('wordlen,K,n', [(8, 500, 2000), (8, 1000, 2000), (15, 500, 2000), (6, 200, 900)])
+def test_local_similarity_vs_oracle(wordlen, K, n):
+    """WordBlot.score_seeds / similar_segments (blot.py:376-490) against the oracle (which runs the reference's
+    KD-tree search and depth-first growth on the CPU): neighbour sets, p per seed (==), segments (==), seed counts;
+    the segment's averaged p within 1e-12 relative -- its last bits follow the KD-tree's internal neighbour order
+    in the reference -- and the z-scores derived from it within 1e-9."""
+    from biseqt_amd import synth
+    from biseqt_amd.blot import WordBlot
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO
+    A = Alphabet('ACGT')
+    gap, subst = .05, .05
+    rng = synth.rng_for(wordlen * 100 + K)
+    hom = synth.rand_seqs(rng, 1, K)[0]
+    S = np.concatenate([hom, synth.rand_seqs(rng, 1, n - K)[0]])
+    T = np.concatenate([synth.mutate(rng, hom, subst, gap, gap), synth.rand_seqs(rng, 1, n - K)[0]])
+    # a second, weaker homology elsewhere so that several segments and thresholds are exercised
+    seg2 = synth.mutate(rng, S[n // 2:n // 2 + 200], .1, .05, .05)[:180]
+    T[n - 300:n - 300 + len(seg2)] = seg2
+    p_match = (1 - gap) * (1 - subst) * .9
+    wb = WordBlot(_mk(A, S), _mk(A, T), g_max=.2, sensitivity=.99, alphabet=A, wordlen=wordlen)
+    for Kq in (K, max(K // 4, 40)):
+        got = wb.score_seeds(Kq)
+        exp = BO.score_seeds_local(S.tolist(), T.tolist(), wordlen, 4, .2, .99, Kq)
+        assert len(got) == len(exp)
+        for g, e in zip(got, exp):
+            assert g['seed'] == e['seed'] and sorted(g['neighs']) == sorted(e['neighs']) and g['p'] == e['p']
+        for p_min in (p_match, .5, .99):
+            gs = list(wb.similar_segments(Kq, p_min))
+            es = BO.similar_segments(S.tolist(), T.tolist(), wordlen, 4, .2, .99, Kq, p_min)
+            assert [g['segment'] for g in gs] == [e['segment'] for e in es], (Kq, p_min)
+            for g, e in zip(gs, es):
+                assert abs(g['p'] - e['p']) <= 1e-12 * max(abs(e['p']), 1e-300)
+                assert np.allclose(g['scores'], e['scores'], rtol=1e-9, atol=0)
+    gs = list(wb.similar_segments(K, 1.5, at_least_one=True))
+    es = BO.similar_segments(S.tolist(), T.tolist(), wordlen, 4, .2, .99, K, 1.5, at_least_one=True)
+    assert len(gs) == len(es) == 1 and gs[0]['segment'] == es[0]['segment']
+    # the reference's own assertions (tests/test_blot.py:117-152) on the main homology
+    homs = list(wb.similar_segments(K, p_match))
+    assert any(h['segment'][0][0] < 10 and h['segment'][0][1] > -10 and h['segment'][1][0] < K
+               and 0.8 * p_match <= h['p'] <= 1.2 * p_match for h in homs)
+    wb.close()

@@ -57,3 +57,18 @@ def test_overlap_detection(wordlen, K, n):          # tests/test_blot.py:160-197
     T = np.concatenate([synth.rand_seqs(rng, 1, n)[0], synth.mutate(rng, overlap, subst, gap, gap), synth.rand_seqs(rng, 1, n - K)[0]])
     rec = BO.highest_scoring_overlap_band(S.tolist(), T.tolist(), wordlen, 4, .2, .99)
     assert rec['p'] < p_match
+
+
+@pytest.mark.parametrize('wordlen,K,n', [(8, 500, 2000), (8, 1000, 2000), (15, 500, 2000)])
+def test_local_similarity(wordlen, K, n):           # tests/test_blot.py:117-152
+    gap, subst = .05, .05
+    rng = synth.rng_for(wordlen * 100 + K)
+    hom = synth.rand_seqs(rng, 1, K)[0]
+    S = np.concatenate([hom, synth.rand_seqs(rng, 1, n - K)[0]])
+    T = np.concatenate([synth.mutate(rng, hom, subst, gap, gap), synth.rand_seqs(rng, 1, n - K)[0]])
+    p_match = (1 - gap) * (1 - subst) * .9
+    homs = BO.similar_segments(S.tolist(), T.tolist(), wordlen, 4, .2, .99, K, p_match)
+    assert len(homs) == 1
+    (d_min, d_max), (a_min, a_max) = homs[0]['segment']
+    assert d_min < 10 and d_max > -10 and a_min < K
+    assert 0.8 * p_match <= homs[0]['p'] <= 1.2 * p_match
