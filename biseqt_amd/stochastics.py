@@ -1,7 +1,7 @@
 """Random sequences, the mutation process and its log-odds scores.
 
-The subset of the reference's ``biseqt/stochastics.py`` that produces inputs and score matrices for
-the alignment path: ``rand_seq`` (:28-41), ``MutationProcess.mutate`` (:143-201) and
+Mirrors the reference's ``biseqt/stochastics.py``: ``rand_seq`` (:28-41), ``rand_read`` (:44-88),
+``MutationProcess.mutate`` (:143-201), ``MutationProcess.noisy_read`` (:203-232) and
 ``MutationProcess.log_odds_scores`` (:234-310).  The log-odds formula defines the floating-point
 scoring case of the aligner.  Randomness comes from a ``numpy.random.Generator`` that callers may
 pass in (``rng=``); the module-level default is seeded from OS entropy like the reference's use of
@@ -24,6 +24,20 @@ def rand_seq(alphabet, size, p=None, rng=None):
     rng = rng or _default_rng
     contents = rng.choice(len(alphabet), size=int(size), p=p)
     return Sequence(alphabet, contents.tolist())
+
+
+def rand_read(seq, len_mean=None, len_sd=1, expected_coverage=None, num=None, rng=None):
+    """Lossless reads of ``seq``: substrings of Gaussian length at uniformly chosen starts; ``num`` reads, or as
+    many as ``expected_coverage`` asks for, or one (``stochastics.py:44-88``).  Yields ``(read, start)``."""
+    assert len_mean < len(seq), 'Expected read length must be smaller than the sequence length'
+    assert num is None or expected_coverage is None, 'At most one of expected_coverage or num can be specified'
+    rng = rng or _default_rng
+    if num is None:
+        num = 1 if expected_coverage is None else int(1. * len(seq) * expected_coverage / len_mean)
+    for length in rng.normal(loc=len_mean, scale=len_sd, size=num):
+        length = max(1, min(len(seq) - 1, int(length)))     # at least 1, at most |S| - 1
+        start = int(rng.choice(len(seq) - length))
+        yield seq[start:start + length], start
 
 
 class MutationProcess(object):
@@ -83,6 +97,14 @@ class MutationProcess(object):
                     pos += 1
             opseq.append(op)
         return Sequence(self.alphabet, T), ''.join(opseq)
+
+    def noisy_read(self, seq, **kw):
+        """:func:`rand_read`, then every read through :func:`mutate` (``stochastics.py:203-232``).  Yields
+        ``(noisy read, start of the lossless read, edit transcript)``."""
+        kw.setdefault('rng', self.rng)
+        for read, start in rand_read(seq, **kw):
+            read, tx = self.mutate(read)
+            yield read, start, tx
 
     def log_odds_scores(self, null_hypothesis=None):
         """Natural-log odds scores of the process (``stochastics.py:234-310``):

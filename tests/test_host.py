@@ -177,3 +177,35 @@ def test_synthetic_batch_is_deterministic():
     o2, m2 = synth.pair_batch(2, 5, 300)
     assert all((a == b).all() for a, b in zip(o1, o2)) and all((a == b).all() for a, b in zip(m1, m2))
     assert all(abs(len(m) - 300) < 60 for m in m1)
+
+
+def test_rand_read_and_noisy_read():
+    """reference tests/test_stochastics.py:19-62 (lossless reads, coverage) and :203-232 (noisy reads)."""
+    from biseqt_amd.stochastics import rand_read
+    rng = np.random.default_rng(4)
+    A = Alphabet('ACGT')
+    S = rand_seq(A, 100, rng=rng)
+    assert len(list(rand_read(S, len_mean=len(S) / 2, expected_coverage=10, rng=rng))) == 20
+    with pytest.raises(AssertionError):
+        next(rand_read(S, len_mean=200, num=1))
+    with pytest.raises(AssertionError):
+        next(rand_read(S, len_mean=50, num=1, expected_coverage=1))
+    assert sum(1 for _ in rand_read(S, len_mean=50, num=10, rng=rng)) == 10
+    assert sum(1 for _ in rand_read(S, len_mean=50, rng=rng)) == 1
+    read, pos = next(rand_read(S, len_mean=40, num=1, rng=rng))
+    assert S[pos:pos + len(read)] == read
+    S3 = A.parse('ACT' * 100)
+    reads = list(rand_read(S3, len_mean=100, len_sd=10, num=100, rng=rng))
+    assert len(set(len(r) for r, _ in reads)) > 1
+    assert 50 < sum(len(r) for r, _ in reads) / 100. < 150
+    A2 = Alphabet(['00', '01'])
+    S2 = A2.parse('01' * 10)
+    r, _ = next(rand_read(S2, len_mean=1, len_sd=1e-9, num=1, rng=rng))
+    assert r == A2.parse('01')
+    M = MutationProcess(A, subst_probs=.1, go_prob=.1, ge_prob=.2, rng=rng)
+    out = list(M.noisy_read(S, len_mean=30, num=5))
+    assert len(out) == 5
+    for noisy, start, tx in out:
+        n_orig = sum(1 for c in tx if c in 'MSD')
+        assert S[start:start + n_orig].contents == S.contents[start:start + n_orig]
+        assert len(noisy) == sum(1 for c in tx if c in 'MSI')
