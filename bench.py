@@ -8,7 +8,9 @@ One "step" = one pass of the hot path (fill + end-cell search + traceback, pw_ba
 pw_batch_traceback) over one batch of 10 000 synthetic 2 kb x ~2 kb pairs, band radius 200, B_LOCAL,
 scores match 1 / mismatch -3 / gap open -5 / gap extend -2, inputs resident in HBM.  With N > 1 every
 rank holds its own batch of the same shape (pairs dealt round-robin from an N-times larger job: weak
-scaling) and each step ends with the gather of the 32-byte result records to rank 0 over RCCL.
+scaling) and each step ends with the gather of the 32-byte result records to rank 0 over RCCL.  Two batches of
+that shape are kept in flight per GPU, each on its own HIP stream, consecutive steps alternating between them
+(--inflight): the traceback is a latency-bound walk, and the other batch's fill hides it.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the fill kernel (the dominant kernel) with the
 algorithmic bytes of SURVEY.md 8d -- 0.5 B per cell (4-bit tie mask) + X + Y + 32 B per pair + the
@@ -113,6 +115,9 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (default: the BASELINE config)')
+    ap.add_argument('--inflight', type=int, default=2,
+                    help='batches in flight per GPU, each on its own HIP stream (consecutive steps alternate); 2 hides the '
+                         'latency-bound traceback of one batch behind the fill of the next (measured: 4.53 -> 3.88 ms/step)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL gather path even with one rank (self-test)')
     args = ap.parse_args()
@@ -140,51 +145,65 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29513')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    # rank r owns pairs r, r + world, ... of a job of world * pairs pairs (round-robin shard)
+    # rank r owns pairs r, r + world, ... of a job of world * pairs pairs (round-robin shard).  `inflight` batches
+    # of that shape (different synthetic pairs) are resident; step i runs batch i % inflight on stream i % inflight.
     n_local = args.pairs
-    origins, mutants = synth.pair_batch(2 + 1000 * rank, n_local, LENGTH)
-    batch = BatchAligner(list(zip(origins, mutants)), alnmode=W.BANDED_MODE, alntype=W.B_LOCAL, alphabet_len=4,
-                         diag_range=(-RADIUS, RADIUS), match_score=SCORES['match'],
-                         mismatch_score=SCORES['mismatch'], go_score=SCORES['go'], ge_score=SCORES['ge'],
-                         device=local_rank, flags=W.PW_FLAG_PROFILE)
+    nfl = max(1, args.inflight)
+    batches, streams = [], []
+    for j in range(nfl):
+        origins, mutants = synth.pair_batch(2 + 1000 * rank + 100 * j, n_local, LENGTH)
+        batches.append(BatchAligner(list(zip(origins, mutants)), alnmode=W.BANDED_MODE, alntype=W.B_LOCAL, alphabet_len=4,
+                                    diag_range=(-RADIUS, RADIUS), match_score=SCORES['match'],
+                                    mismatch_score=SCORES['mismatch'], go_score=SCORES['go'], ge_score=SCORES['ge'],
+                                    device=local_rank, flags=W.PW_FLAG_PROFILE))
+        streams.append(torch.cuda.Stream(device=dev))
+    batch = batches[0]
     cells = batch.cells
-    stream = torch.cuda.current_stream().cuda_stream
-    res_dev = torch.as_tensor(batch.results_device(), device=dev) if use_dist else None
-    gathered = [torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] \
+    res_devs = [torch.as_tensor(b.results_device(), device=dev) for b in batches] if use_dist else None
+    gathered = [[torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(nfl)] \
         if (use_dist and rank == 0) else None
 
-    def step():
-        batch.solve(stream)
-        batch.traceback(stream)
-        if use_dist:
-            dist.gather(res_dev, gathered, dst=0)
+    def step(i):
+        j = i % nfl
+        with torch.cuda.stream(streams[j]):
+            s = streams[j].cuda_stream
+            batches[j].solve(s)
+            batches[j].traceback(s)
+            if use_dist:
+                dist.gather(res_devs[j], gathered[j] if rank == 0 else None, dst=0)
+        return batches[j].cells
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     fill_ms, trace_ms = [], []
+    done_cells = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        done_cells += step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    # per-kernel durations (HIP events recorded by the library on the launch stream): sample a few
-    # extra steps outside the timed region so that reading the events never stalls the pipeline
+    # per-kernel durations (HIP events recorded by the library on the launch stream): sample a few extra steps of
+    # ONE batch alone, outside the timed region, so that the kernel time is not stretched by the other batch
+    stream = streams[0].cuda_stream
     for _ in range(min(5, max(1, args.steps))):
         batch.solve(stream)
         batch.traceback(stream)
         batch.sync(stream)
         fill_ms.append(batch.fill_ms())
         trace_ms.append(batch.trace_ms())
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, float(done_cells)], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        tm = t[:1].clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        tc = t[1:].clone(); dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+        elapsed, total_done = float(tm.item()), float(tc.item())
+    else:
+        total_done = float(done_cells)
 
     res = batch.results()
     tx_bytes = int(res['tx_len'].sum())
@@ -194,8 +213,7 @@ def main():
     ok = bool((res['status'] & 1).all() and (res['opt_i'] >= 0).all())
 
     if rank == 0:
-        total_cells = cells * world
-        value = total_cells * args.steps / elapsed / 1e9
+        value = total_done / elapsed / 1e9          # cells of every step of every rank / max-over-ranks time
         achieved = alg_bytes / (fill * 1e-3) / 1e9
         line = {
             'metric': 'GCUPS (DP cell updates/s) banded local align',
@@ -206,10 +224,11 @@ def main():
             'dtype': 'i16' if 'k_fill16' in batch.kernel_name else ('i32' if batch.score_dtype == 'i32' else 'f64'),
             'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[1]: %d pairs/GPU, %d x ~%d, band radius %d, B_LOCAL, '
-                                   'match 1 / mismatch -3 / go -5 / ge -2, fill + end-cell search + traceback%s'
+                                   'match 1 / mismatch -3 / go -5 / ge -2, fill + end-cell search + traceback%s; '
+                                   '%d batches in flight per GPU on separate HIP streams'
                                    % (n_local, LENGTH, LENGTH, RADIUS,
-                                      ' + RCCL gather of result records' if world > 1 else ''),
-                       'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'parallelism': 'pairs round-robin x%d' % world},
+                                      ' + RCCL gather of result records' if world > 1 else '', nfl),
+                       'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'batches_in_flight': nfl, 'parallelism': 'pairs round-robin x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(batch.kernel_name, n_local),
                          'kernel': batch.kernel_name,
@@ -223,9 +242,10 @@ def main():
         print(json.dumps(line))
     if use_dist and rank == 0:
         # the gathered records of rank 0 must be this rank's device records, bit for bit
-        got = gathered[0].cpu().numpy().view(RESULT_DTYPE)
+        got = gathered[0][0].cpu().numpy().view(RESULT_DTYPE)
         assert (got == res).all(), 'gathered records differ from the local results'
-    batch.close()
+    for b in batches:
+        b.close()
     if use_dist:
         dist.destroy_process_group()
 

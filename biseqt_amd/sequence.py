@@ -87,7 +87,13 @@ class Sequence(object):
 
     def as_array(self, dtype=np.uint8):
         """The contents as a numpy array (one byte per letter is what the device arena holds)."""
-        return np.asarray(self.contents, dtype=dtype)
+        cache = self.__dict__.setdefault('_arrays', {})           # contents are immutable
+        key = np.dtype(dtype).str
+        if key not in cache:
+            arr = np.asarray(self.contents, dtype=dtype)
+            arr.setflags(write=False)
+            cache[key] = arr
+        return cache[key]
 
     def reverse(self):
         return Sequence(self.alphabet, tuple(reversed(self.contents)))

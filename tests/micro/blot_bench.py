@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from biseqt_amd import synth                        # noqa: E402
 from biseqt_amd.blot import WordBlot                # noqa: E402
+from biseqt_amd.pipeline import extend_segments     # noqa: E402
 from biseqt_amd.sequence import Alphabet, Sequence  # noqa: E402
 
 
@@ -55,6 +56,18 @@ def main():
     print('planted homologies recovered: %d / %d; first segments:' % (hit, len(planted)))
     for sg in segs[:3]:
         print('  ', sg['segment'], 'p=%.3f' % sg['p'], 'z=(%.1f, %.1f)' % sg['scores'])
+    # banded DP extension of every segment (experiments/blot_stats.py:438-470), one batch
+    p_min = .7
+    kw = dict(match_score=1. / p_min - 1, mismatch_score=-1, ge_score=-1, go_score=0)
+    extend_segments(S, T, segs[:2], k, **kw)
+    t5 = time.perf_counter()
+    ext = extend_segments(S, T, segs, k, **kw)
+    t6 = time.perf_counter()
+    cells = sum((2 * r['diag_range'][1] + 1) * min(r['frame'][0][1] - r['frame'][0][0], r['frame'][1][1] - r['frame'][1][0]) for r in ext)
+    ok = sum(1 for r in ext if r['truncated'] is not None)
+    ident = [r['truncated'].transcript.count('M') / float(len(r['truncated'].transcript)) for r in ext if r['truncated'] is not None]
+    print('banded extension of %d segments (f64 scores, B_GLOBAL): %.3f s wall incl. planning and D2H, ~%.2e cells; %d alignments, identity %.3f..%.3f'
+          % (len(ext), t6 - t5, cells, ok, min(ident), max(ident)))
     wb.close()
 
 
