@@ -127,6 +127,14 @@ SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_se
                 'pw_seeds_algorithmic_bytes', 'pw_seeds_destroy', 'pw_seeds_last_error']
 
 
+# every symbol include/pw_overlap.h declares
+OVERLAP_EXPORTS = ['pw_overlap_bands', 'pw_overlap_last_ms', 'pw_overlap_last_error']
+
+
+class pw_read_pair(C.Structure):
+    _fields_ = [('s_off', C.c_uint64), ('t_off', C.c_uint64), ('s_len', C.c_int32), ('t_len', C.c_int32)]
+
+
 def check_layout():
     for name, size in SIZEOF.items():
         assert C.sizeof(globals()[name]) == size, (name, C.sizeof(globals()[name]), size)
@@ -219,6 +227,11 @@ def load():
     lib.pw_seeds_destroy.argtypes = [C.c_void_p]
     lib.pw_seeds_destroy.restype = None
     lib.pw_seeds_last_error.restype = C.c_char_p
+    # include/pw_overlap.h
+    lib.pw_overlap_bands.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                     C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.pw_overlap_last_ms.restype = C.c_double
+    lib.pw_overlap_last_error.restype = C.c_char_p
     _lib = lib
     return lib
 

@@ -58,6 +58,9 @@ def _jobs():
     obj = os.path.join(OBJ_DIR, 'pw_seeds.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-Wno-unused-parameter', '-c', os.path.join(HERE, 'pw_seeds.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_seeds.hip'), os.path.join(ROOT, 'include', 'pw_seeds.h')]))
+    obj = os.path.join(OBJ_DIR, 'pw_overlap.o')
+    jobs.append((obj, [HIPCC] + COMMON + ['-Wno-unused-parameter', '-c', os.path.join(HERE, 'pw_overlap.hip'), '-o', obj],
+                 [os.path.join(HERE, 'pw_overlap.hip'), os.path.join(ROOT, 'include', 'pw_overlap.h')]))
     obj = os.path.join(OBJ_DIR, 'pwlib_api.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-x', 'hip', '-c', os.path.join(HERE, 'pwlib_api.cpp'), '-o', obj],
                  [os.path.join(HERE, 'pwlib_api.cpp'), os.path.join(ROOT, 'include', 'pwlib.h'),

@@ -1,0 +1,312 @@
+// pw_overlap.hip -- overlap band selection for many read pairs at once (C ABI: include/pw_overlap.h).
+//
+//   K8a k_enc_batch   k-mer of every position of every pair's S (or T) read, key = (pair << kbits) | k-mer
+//       sort          both sides by key (rocPRIM radix sort, stable: positions ascending inside a k-mer)
+//   K8b k_join_hist   one thread per sorted S element: its run of equal keys on the T side; every (i, j) of the run
+//                     is one seed: atomicAdd into the pair's per-diagonal histogram (rows are never written), the
+//                     pair's row count, and atomicMin of the element index (-> the first row in table order)
+//   K8c k_band_select one workgroup per pair: prefix sums of the histogram, then for every occupied diagonal the
+//                     window of diagonals within 1 on the axis d / r(d) (binary searches on the reference's own
+//                     floating-point predicate; d / r(d) is monotone in d), n(d), w(d); block reduction to the
+//                     best diagonal, the tie count and the seed count of its band
+// All floating point is IEEE double in the reference's operation order (compiled with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <cstring>
+#include <algorithm>
+#include <string>
+#include <vector>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/pw_overlap.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local double g_ms = 0.0;
+void set_err(const std::string& s) { g_err = s; }
+#define OV_CHECK(call)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err(std::string(#call) + ": " + hipGetErrorString(e_));                            \
+      return -1;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+struct DPair { uint64_t s_off, t_off; int32_t s_len, t_len; uint64_t hbase; };   // hbase: start of its histogram
+
+__device__ __forceinline__ int64_t ub_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {   // first > key
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int64_t lb_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {   // first >= key
+  int64_t lo = 0, hi = n;
+  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// side 0: S reads, side 1: T reads.  start[p] = index of pair p's first k-mer on this side (start[n] = total).
+__global__ __launch_bounds__(256) void k_enc_batch(const uint8_t* __restrict__ arena, const DPair* __restrict__ pairs,
+                                                   const uint64_t* __restrict__ start, int64_t npairs, int64_t total, int side,
+                                                   int k, int L, int kbits, uint64_t* __restrict__ keys, uint32_t* __restrict__ pos) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int64_t p = ub_u64(start, npairs + 1, (uint64_t)g) - 1;
+  const DPair pr = pairs[p];
+  const uint32_t q = (uint32_t)(g - (int64_t)start[p]);
+  const uint8_t* __restrict__ s = arena + (side ? pr.t_off : pr.s_off) + q;
+  uint64_t v = 0;
+  for (int t = 0; t < k; t++) v = v * (uint64_t)L + s[t];
+  keys[g] = ((uint64_t)p << kbits) | v;
+  pos[g] = q;
+}
+
+__global__ __launch_bounds__(256) void k_join_hist(const uint64_t* __restrict__ ks, const uint32_t* __restrict__ ps, int64_t ns,
+                                                   const uint64_t* __restrict__ kt, const uint32_t* __restrict__ pt, int64_t nt,
+                                                   const DPair* __restrict__ pairs, int kbits, uint32_t* __restrict__ hist,
+                                                   unsigned long long* __restrict__ nrows, uint32_t* __restrict__ first_e) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= ns) return;
+  const uint64_t key = ks[e];
+  const int64_t lo = lb_u64(kt, nt, key);
+  if (lo >= nt || kt[lo] != key) return;
+  const int64_t hi = ub_u64(kt, nt, key);
+  const int64_t p = (int64_t)(key >> kbits);
+  const DPair pr = pairs[p];
+  const int i = (int)ps[e];
+  uint32_t* __restrict__ h = hist + pr.hbase + pr.t_len;      // h[d], d = -t_len .. s_len
+  for (int64_t t = lo; t < hi; t++) atomicAdd(&h[i - (int)pt[t]], 1u);
+  atomicAdd(&nrows[p], (unsigned long long)(hi - lo));
+  atomicMin(&first_e[p], (uint32_t)e);                        // (fewer than 2^32 k-mers per chunk, checked by the host)
+}
+
+struct BandConst { double q, C, p0; };
+__device__ __forceinline__ int ov_len(int d, int ls, int lt, double q) {
+  const int wall = (ls - d < lt ? ls - d : lt) + (d < 0 ? d : 0);
+  return (int)ceil(q * (double)wall);
+}
+__device__ __forceinline__ int ov_rad(int L, double C) {
+  const int r = (int)ceil(C * sqrt((double)L));
+  return r < 1 ? 1 : r;
+}
+__device__ __forceinline__ double ov_x(int d, int ls, int lt, BandConst c) {
+  return (double)d / (double)ov_rad(ov_len(d, ls, lt, c.q), c.C);
+}
+
+// one workgroup per pair
+__global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* __restrict__ hist,
+                                                     const unsigned long long* __restrict__ nrows, const uint32_t* __restrict__ first_e,
+                                                     const uint64_t* __restrict__ ks, const uint32_t* __restrict__ ps,
+                                                     const uint64_t* __restrict__ kt, const uint32_t* __restrict__ pt, int64_t nt,
+                                                     BandConst c, pw_overlap_band* __restrict__ out) {
+  __shared__ uint32_t s_sum[256];
+  __shared__ double s_w[256];
+  __shared__ int s_d[256], s_cnt[256];
+  const int p = (int)blockIdx.x, tid = (int)threadIdx.x;
+  const DPair pr = pairs[p];
+  const int ls = pr.s_len, lt = pr.t_len, nd = ls + lt + 1;
+  uint32_t* __restrict__ h = hist + pr.hbase;          // index dd = d + lt
+  pw_overlap_band o;
+  memset(&o, 0, sizeof o);
+  o.n_seeds = (int64_t)nrows[p];
+  if (o.n_seeds == 0) { if (tid == 0) out[p] = o; return; }
+  // ---- inclusive prefix sums in place: every thread owns a contiguous chunk ----
+  const int chunk = (nd + 255) / 256;
+  const int b = tid * chunk, e = b + chunk < nd ? b + chunk : nd;
+  uint32_t sum = 0;
+  for (int dd = b; dd < e; dd++) sum += h[dd];
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = tid >= off ? s_sum[tid - off] : 0u;
+    __syncthreads();
+    s_sum[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? s_sum[tid - 1] : 0u;
+  for (int dd = b; dd < e; dd++) { run += h[dd]; h[dd] = run; }
+  __threadfence_block();
+  __syncthreads();
+  auto pre = [&](int dd) -> uint32_t { return dd < 0 ? 0u : h[dd < nd ? dd : nd - 1]; };
+  // neighbours of a seed on diagonal d and the score of its band
+  auto eval = [&](int d, int& n, int& L, int& r) -> double {
+    L = ov_len(d, ls, lt, c.q); r = ov_rad(L, c.C);
+    const double x = (double)d / (double)r;
+    int lo = -lt, hi = d;                              // smallest d' with x - x(d') <= 1
+    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (!(x - ov_x(mid, ls, lt, c) <= 1.0)) lo = mid + 1; else hi = mid; }
+    const int first = lo;
+    lo = d; hi = ls;                                   // largest d' with x(d') - x <= 1
+    while (lo < hi) { const int mid = lo + ((hi - lo + 1) >> 1); if (ov_x(mid, ls, lt, c) - x <= 1.0) lo = mid; else hi = mid - 1; }
+    n = (int)(pre(lo + lt) - pre(first + lt - 1)) - 1;
+    const long long area = 2ll * r * L;
+    return ((double)(n + 1) - (double)area * c.p0) / (double)L;
+  };
+  // ---- pass 1: the best occupied diagonal (largest w, then smallest d) ----
+  double bw = 0.0; int bd = 0x7fffffff;
+  for (int dd = b; dd < e; dd++) {
+    if (pre(dd) == pre(dd - 1)) continue;
+    int n, L, r;
+    const double w = eval(dd - lt, n, L, r);
+    if (bd == 0x7fffffff || w > bw) { bw = w; bd = dd - lt; }
+  }
+  s_w[tid] = bw; s_d[tid] = bd;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) {
+      const double ow = s_w[tid + off]; const int od = s_d[tid + off];
+      const bool have = s_d[tid] != 0x7fffffff, ohave = od != 0x7fffffff;
+      if (ohave && (!have || ow > s_w[tid] || (ow == s_w[tid] && od < s_d[tid]))) { s_w[tid] = ow; s_d[tid] = od; }
+    }
+    __syncthreads();
+  }
+  const double wbest = s_w[0]; const int dbest = s_d[0];
+  __syncthreads();
+  // ---- pass 2: how many occupied diagonals could reach the same p ----
+  int ties = 0;
+  const double thr = wbest >= 1.0 ? 1.0 : wbest - fabs(wbest) * 1e-9;
+  for (int dd = b; dd < e; dd++) {
+    if (pre(dd) == pre(dd - 1)) continue;
+    int n, L, r;
+    const double w = eval(dd - lt, n, L, r);
+    ties += (wbest <= 0.0 || w >= thr) ? 1 : 0;
+  }
+  s_cnt[tid] = ties;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) { if (tid < off) s_cnt[tid] += s_cnt[tid + off]; __syncthreads(); }
+  if (tid == 0) {
+    int n, L, r;
+    o.w_best = eval(dbest, n, L, r);
+    o.d_best = dbest; o.n_best = n; o.len_best = L; o.r_best = r;
+    o.band_best = (int)(pre(dbest + r + lt) - pre(dbest - r + lt - 1));
+    o.tie = s_cnt[0];
+    // first row of the table: the first sorted S element with a match, paired with the first j of its run
+    const uint32_t fe = first_e[p];
+    const int64_t lo = lb_u64(kt, nt, ks[fe]);
+    const int df = (int)ps[fe] - (int)pt[lo];
+    (void)eval(df, n, L, r);
+    o.d_first = df; o.n_first = n; o.len_first = L; o.r_first = r;
+    o.band_first = (int)(pre(df + r + lt) - pre(df - r + lt - 1));
+    out[p] = o;
+  }
+}
+
+struct Buf {
+  void* p = nullptr;
+  int alloc(size_t bytes) { OV_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return 0; }
+  ~Buf() { if (p) (void)hipFree(p); }
+};
+
+int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int L, int k, int kbits, BandConst bc,
+              pw_overlap_band* out, hipEvent_t ev0, hipEvent_t ev1, float* ms) {
+  std::vector<DPair> hp((size_t)n);
+  std::vector<uint64_t> ss((size_t)n + 1), ts((size_t)n + 1);
+  uint64_t hb = 0, cs = 0, ct = 0;
+  for (int64_t p = 0; p < n; p++) {
+    hp[(size_t)p] = DPair{pairs[p].s_off, pairs[p].t_off, pairs[p].s_len, pairs[p].t_len, hb};
+    hb += (uint64_t)pairs[p].s_len + (uint64_t)pairs[p].t_len + 1;
+    ss[(size_t)p] = cs; ts[(size_t)p] = ct;
+    cs += pairs[p].s_len >= k ? (uint64_t)(pairs[p].s_len - k + 1) : 0;
+    ct += pairs[p].t_len >= k ? (uint64_t)(pairs[p].t_len - k + 1) : 0;
+  }
+  ss[(size_t)n] = cs; ts[(size_t)n] = ct;
+  Buf dp, dss, dts, kin, pin, ksb, psb, ktb, ptb, hist, rows, first, dout, tmp;
+  if (dp.alloc(sizeof(DPair) * (size_t)n) || dss.alloc(8 * ((size_t)n + 1)) || dts.alloc(8 * ((size_t)n + 1)) ||
+      kin.alloc(8 * (size_t)std::max(cs, ct)) || pin.alloc(4 * (size_t)std::max(cs, ct)) || ksb.alloc(8 * (size_t)cs) ||
+      psb.alloc(4 * (size_t)cs) || ktb.alloc(8 * (size_t)ct) || ptb.alloc(4 * (size_t)ct) || hist.alloc(4 * (size_t)hb) ||
+      rows.alloc(8 * (size_t)n) || first.alloc(4 * (size_t)n) || dout.alloc(sizeof(pw_overlap_band) * (size_t)n)) return -1;
+  OV_CHECK(hipMemcpy(dp.p, hp.data(), sizeof(DPair) * (size_t)n, hipMemcpyHostToDevice));
+  OV_CHECK(hipMemcpy(dss.p, ss.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice));
+  OV_CHECK(hipMemcpy(dts.p, ts.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice));
+  OV_CHECK(hipEventRecord(ev0, nullptr));
+  OV_CHECK(hipMemsetAsync(hist.p, 0, 4 * (size_t)hb, nullptr));
+  OV_CHECK(hipMemsetAsync(rows.p, 0, 8 * (size_t)n, nullptr));
+  OV_CHECK(hipMemsetAsync(first.p, 0xff, 4 * (size_t)n, nullptr));
+  int pbits = 1; while (((uint64_t)n >> pbits) != 0) pbits++;
+  size_t tb = 0, tb2 = 0;
+  for (int side = 0; side < 2; side++) {
+    const uint64_t tot = side ? ct : cs;
+    if (tot == 0) continue;
+    hipLaunchKernelGGL(k_enc_batch, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, d_arena, (const DPair*)dp.p,
+                       (const uint64_t*)(side ? dts.p : dss.p), n, (int64_t)tot, side, k, L, kbits, (uint64_t*)kin.p, (uint32_t*)pin.p);
+    uint64_t* ko = (uint64_t*)(side ? ktb.p : ksb.p); uint32_t* po = (uint32_t*)(side ? ptb.p : psb.p);
+    OV_CHECK(rocprim::radix_sort_pairs(nullptr, tb2, (const uint64_t*)kin.p, ko, (const uint32_t*)pin.p, po, (size_t)tot, 0u,
+                                       (unsigned)(kbits + pbits), (hipStream_t) nullptr));
+    if (tb2 > tb) { if (tmp.p) { (void)hipFree(tmp.p); tmp.p = nullptr; } if (tmp.alloc(tb2)) return -1; tb = tb2; }
+    OV_CHECK(rocprim::radix_sort_pairs(tmp.p, tb2, (const uint64_t*)kin.p, ko, (const uint32_t*)pin.p, po, (size_t)tot, 0u,
+                                       (unsigned)(kbits + pbits), (hipStream_t) nullptr));
+  }
+  if (cs && ct)
+    hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((cs + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t*)ksb.p,
+                       (const uint32_t*)psb.p, (int64_t)cs, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
+                       (const DPair*)dp.p, kbits, (uint32_t*)hist.p, (unsigned long long*)rows.p, (uint32_t*)first.p);
+  hipLaunchKernelGGL(k_band_select, dim3((unsigned)n), dim3(256), 0, nullptr, (const DPair*)dp.p, (uint32_t*)hist.p,
+                     (const unsigned long long*)rows.p, (const uint32_t*)first.p, (const uint64_t*)ksb.p, (const uint32_t*)psb.p,
+                     (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct, bc, (pw_overlap_band*)dout.p);
+  OV_CHECK(hipEventRecord(ev1, nullptr));
+  OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)n, hipMemcpyDeviceToHost));
+  OV_CHECK(hipGetLastError());
+  float t = 0.f;
+  OV_CHECK(hipEventElapsedTime(&t, ev0, ev1));
+  *ms += t;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pw_overlap_last_error(void) { return g_err.c_str(); }
+double pw_overlap_last_ms(void) { return g_ms; }
+
+int pw_overlap_bands(int device, const uint8_t* arena, uint64_t arena_bytes, const pw_read_pair* pairs, int64_t n_pairs,
+                     int alphabet_len, int wordlen, double len_coeff, double radius_coeff, double word_p_null,
+                     pw_overlap_band* out) {
+  static_assert(sizeof(pw_overlap_band) == 64, "pw_overlap_band is 64 bytes");
+  if (alphabet_len < 1 || alphabet_len > 36 || wordlen < 1 || wordlen > 31) { set_err("alphabet_len 1..36, wordlen 1..31"); return -1; }
+  if (n_pairs < 0 || (n_pairs && (!pairs || !out))) { set_err("bad arguments"); return -1; }
+  if (!(len_coeff > 0) || !(radius_coeff > 0) || !(word_p_null > 0)) { set_err("coefficients must be positive"); return -1; }
+  uint64_t kmax = 1; int kbits = 0;
+  for (int i = 0; i < wordlen; i++) { if (kmax > (1ull << 62) / (uint64_t)alphabet_len) { set_err("alphabet_len ^ wordlen must be below 2^62"); return -1; } kmax *= (uint64_t)alphabet_len; }
+  while (((kmax - 1) >> kbits) != 0) kbits++;
+  if (kbits == 0) kbits = 1;
+  for (int64_t p = 0; p < n_pairs; p++) {
+    const pw_read_pair& r = pairs[p];
+    if (r.s_len < 0 || r.t_len < 0 || r.s_off + (uint64_t)r.s_len > arena_bytes || r.t_off + (uint64_t)r.t_len > arena_bytes) {
+      set_err("a read lies outside the arena"); return -1;
+    }
+  }
+  for (uint64_t i = 0; i < arena_bytes; i++) if (arena[i] >= alphabet_len) { set_err("letter outside the alphabet"); return -1; }
+  g_ms = 0.0;
+  if (n_pairs == 0) return 0;
+  OV_CHECK(hipSetDevice(device));
+  Buf d_arena;
+  if (d_arena.alloc((size_t)arena_bytes + 64)) return -1;
+  OV_CHECK(hipMemcpy(d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice));
+  hipEvent_t ev0, ev1;
+  OV_CHECK(hipEventCreate(&ev0)); OV_CHECK(hipEventCreate(&ev1));
+  // chunks: at most 2^31 histogram entries, 2^31 k-mers per side and pair ids that fit beside the k-mer
+  const uint64_t lim = 1ull << 31;
+  const int64_t max_pairs_bits = 62 - kbits;
+  float ms = 0.f;
+  int rc = 0;
+  for (int64_t p0 = 0; p0 < n_pairs && rc == 0;) {
+    uint64_t hb = 0, cs = 0, ct = 0; int64_t p1 = p0;
+    while (p1 < n_pairs) {
+      const uint64_t h = (uint64_t)pairs[p1].s_len + (uint64_t)pairs[p1].t_len + 1;
+      if (p1 > p0 && (hb + h > lim || cs + (uint64_t)pairs[p1].s_len > lim || ct + (uint64_t)pairs[p1].t_len > lim ||
+                      (max_pairs_bits < 40 && (p1 - p0 + 1) >= (1ll << max_pairs_bits)))) break;
+      hb += h; cs += (uint64_t)pairs[p1].s_len; ct += (uint64_t)pairs[p1].t_len; p1++;
+    }
+    rc = run_chunk((const uint8_t*)d_arena.p, pairs + p0, p1 - p0, alphabet_len, wordlen, kbits,
+                   BandConst{len_coeff, radius_coeff, word_p_null}, out + p0, ev0, ev1, &ms);
+    p0 = p1;
+  }
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  g_ms = (double)ms;
+  return rc;
+}
+
+}  // extern "C"

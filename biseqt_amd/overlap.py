@@ -1,0 +1,137 @@
+"""Overlap discovery for many read pairs: band selection in one GPU pass, then one banded overlap-alignment batch.
+
+The reference scores every pair of reads with its own ``WordBlotOverlap`` object
+(``experiments/blot_overlaps.py:262-272``, ``biseqt/blot.py:497-579``).  :func:`overlap_bands` returns, per pair, the
+same dict ``highest_scoring_overlap_band()`` returns (``d_band``, ``p``, ``len``, ``score``; None without seeds), all
+pairs scored by one call into ``include/pw_overlap.h``; :func:`overlap_alignments` then gives every band to the
+banded overlap aligner (``B_OVERLAP``) in one batch -- BASELINE config 4's "seeding -> banded DP".
+Pairs for which more than one diagonal could reach the same estimated match probability (where the reference's
+answer depends on the order of its seeds table) are re-scored by the single-pair path, which reproduces that order.
+One documented divergence: two reads with IDENTICAL content are scored here as two different sequences, whereas the
+reference turns such a pair into a self comparison (``seeds.py:33``) and ignores its main diagonal.
+"""
+import ctypes as C
+
+import numpy as np
+from scipy.special import erfcinv
+
+from . import _pwlib as W
+from .batch import BatchAligner
+from .blot import H1_moments, WordBlotOverlap
+from .sequence import Alphabet, Sequence
+
+BAND_DTYPE = np.dtype([('n_seeds', '<i8'), ('w_best', '<f8'), ('d_best', '<i4'), ('n_best', '<i4'),
+                       ('r_best', '<i4'), ('len_best', '<i4'), ('band_best', '<i4'), ('tie', '<i4'),
+                       ('d_first', '<i4'), ('n_first', '<i4'), ('r_first', '<i4'), ('len_first', '<i4'),
+                       ('band_first', '<i4'), ('pad_', '<i4')])
+assert BAND_DTYPE.itemsize == 64
+
+
+def _arena(reads):
+    arrs = [r.as_array(np.uint8) if isinstance(r, Sequence) else np.ascontiguousarray(r, np.uint8) for r in reads]
+    offs = np.zeros(len(arrs) + 1, np.int64)
+    offs[1:] = np.cumsum([len(a) for a in arrs])
+    arena = np.concatenate(arrs) if arrs else np.zeros(0, np.uint8)
+    return arena, offs, arrs
+
+
+def _same(a, b):
+    a = a.as_array(np.uint8) if isinstance(a, Sequence) else np.asarray(a)
+    b = b.as_array(np.uint8) if isinstance(b, Sequence) else np.asarray(b)
+    return len(a) == len(b) and bool((a == b).all())
+
+
+def raw_bands(reads, pairs, wordlen, alphabet_len, g_max, sensitivity, device=0):
+    """The device records (BAND_DTYPE) for ``pairs`` = list of (i, j) indices into ``reads``; also returns the
+    device time in ms."""
+    assert 0 < g_max < 1 and 0 < sensitivity < 1
+    lib = W.load()
+    arena, offs, arrs = _arena(reads)
+    n = len(pairs)
+    rp = (W.pw_read_pair * max(n, 1))()
+    for q, (i, j) in enumerate(pairs):
+        rp[q] = W.pw_read_pair(int(offs[i]), int(offs[j]), len(arrs[i]), len(arrs[j]))
+    out = np.zeros(max(n, 1), BAND_DTYPE)
+    # the reference's constants, computed as it computes them (blot.py:109, 134-136, 538)
+    len_coeff = 2. / (2 - g_max)
+    radius_coeff = erfcinv(1. - sensitivity) * np.sqrt(2 * g_max)
+    word_p_null = (1. / alphabet_len) ** wordlen
+    arena_c = np.ascontiguousarray(arena)
+    rc = lib.pw_overlap_bands(device, arena_c.ctypes.data, arena_c.size, rp, n, alphabet_len, wordlen,
+                              float(len_coeff), float(radius_coeff), float(word_p_null), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError('pw_overlap_bands failed: ' + (lib.pw_overlap_last_error() or b'').decode())
+    return out[:n], lib.pw_overlap_last_ms()
+
+
+def _result(d, rad, L, n_in_band, word_p, alphabet_len, wordlen):
+    if not word_p > 0:                                   # blot.py:541-545
+        p_hat = 0
+    else:
+        p_hat = np.exp(np.log(word_p) / wordlen)
+    p_hat = min(p_hat, 1)
+    rad = np.float64(rad)                                # the reference carries np.ceil's float
+    res = {'d_band': (d - rad, d + rad), 'p': p_hat, 'len': int(L)}
+    area = 2 * rad * L
+    mu_H1, sd_H1 = H1_moments(alphabet_len, wordlen, area, L, p_hat)
+    res['score'] = (n_in_band - mu_H1) / sd_H1
+    return res
+
+
+def overlap_bands(reads, pairs, wordlen, alphabet, g_max, sensitivity, device=0, stats=None):
+    """``highest_scoring_overlap_band()`` of every pair ``(i, j)`` (``reads[i]`` as S, ``reads[j]`` as T)."""
+    assert isinstance(alphabet, Alphabet)
+    L = len(alphabet)
+    recs, ms = raw_bands(reads, pairs, wordlen, L, g_max, sensitivity, device)
+    out, n_fallback = [], 0
+    for q, r in enumerate(recs):
+        if r['n_seeds'] == 0:
+            out.append(None)
+        elif not r['w_best'] > 0:
+            # every p is 0: max() keeps the first row of the table (blot.py:569)
+            word_p = (r['n_first'] + 1 - (2 * int(r['r_first']) * int(r['len_first'])) * ((1. / L) ** wordlen)) / r['len_first']
+            out.append(_result(int(r['d_first']), int(r['r_first']), int(r['len_first']), int(r['band_first']), word_p, L, wordlen))
+        elif r['tie'] > 1 and not _same(reads[pairs[q][0]], reads[pairs[q][1]]):
+            i, j = pairs[q]
+            S = reads[i] if isinstance(reads[i], Sequence) else Sequence(alphabet, tuple(int(c) for c in reads[i]))
+            T = reads[j] if isinstance(reads[j], Sequence) else Sequence(alphabet, tuple(int(c) for c in reads[j]))
+            wb = WordBlotOverlap(S, T, g_max=g_max, sensitivity=sensitivity, alphabet=alphabet, wordlen=wordlen, device=device)
+            out.append(wb.highest_scoring_overlap_band())
+            wb.close()
+            n_fallback += 1
+        else:
+            out.append(_result(int(r['d_best']), int(r['r_best']), int(r['len_best']), int(r['band_best']), float(r['w_best']), L, wordlen))
+    if stats is not None:
+        stats.update(device_ms=ms, fallback_pairs=n_fallback, pairs=len(pairs))
+    return out
+
+
+def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, **aligner_kw):
+    """Banded overlap alignment (``B_OVERLAP``) of every pair whose band has ``p >= p_min``, all in one batch; the
+    ``diag_range`` is the band clamped to the table as ``Aligner`` requires (``pw.py:224-226``).  Returns a list with
+    one entry per pair: None, or dict(score, transcript, origin_start, mutant_start, diag_range)."""
+    arrs = [r.as_array(np.uint8) if isinstance(r, Sequence) else np.ascontiguousarray(r, np.uint8) for r in reads]
+    sel, bp, dr = [], [], []
+    for q, ((i, j), band) in enumerate(zip(pairs, bands)):
+        if band is None or band['p'] < p_min:
+            continue
+        lo = max(int(band['d_band'][0]), -len(arrs[j]))
+        hi = min(int(band['d_band'][1]), len(arrs[i]))
+        if lo > hi:
+            continue
+        sel.append(q); bp.append((arrs[i], arrs[j])); dr.append((lo, hi))
+    out = [None] * len(pairs)
+    if not sel:
+        return out
+    kw = dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
+    kw.update(aligner_kw)
+    with BatchAligner(bp, alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP, alphabet_len=len(alphabet), diag_range=dr,
+                      device=device, **kw) as b:
+        res = b.run()
+        txs = b.transcripts(res)
+    for k, q in enumerate(sel):
+        if res['opt_i'][k] < 0:
+            continue
+        out[q] = dict(score=float(res['score'][k]), transcript=txs[k], origin_start=int(res['origin_idx'][k]),
+                      mutant_start=int(res['mutant_idx'][k]), diag_range=dr[k])
+    return out

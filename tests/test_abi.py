@@ -17,7 +17,7 @@ def _declared_functions(header):
     txt = open(os.path.join(ROOT, 'include', header)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     txt = re.sub(r'//[^\n]*', '', txt)
-    return set(re.findall(r'\b(dptable_\w+|pw_\w+)\s*\(', txt)) - {'pw_batch', 'pw_seed_index'}
+    return set(re.findall(r'\b(dptable_\w+|pw_\w+)\s*\(', txt)) - {'pw_batch', 'pw_seed_index', 'pw_read_pair', 'pw_overlap_band'}
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -31,6 +31,11 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert seeds == set(W.SEED_EXPORTS), seeds ^ set(W.SEED_EXPORTS)
     for name in seeds:
         assert hasattr(lib, name), name
+    ov = _declared_functions('pw_overlap.h')
+    assert ov == set(W.OVERLAP_EXPORTS), ov ^ set(W.OVERLAP_EXPORTS)
+    for name in ov:
+        assert hasattr(lib, name), name
+    assert C.sizeof(W.pw_read_pair) == 24
 
 
 def test_struct_layouts_match_reference_abi():

@@ -1,0 +1,81 @@
+"""Batched overlap band selection (include/pw_overlap.h through biseqt_amd.overlap) against the oracle's
+highest_scoring_overlap_band of every pair (which runs the reference's KD-tree search on the CPU), then the
+config-4 flow: bands -> one banded overlap-alignment batch, alignments equal to the C oracle's."""
+import itertools
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(rng, genome_len, n_reads, read_len, subst, gap):
+    from biseqt_amd import synth
+    g = synth.rand_seqs(rng, 1, genome_len)[0]
+    reads, starts = [], []
+    for _ in range(n_reads):
+        st = int(rng.integers(0, genome_len - read_len))
+        reads.append(synth.mutate(rng, g[st:st + read_len], subst, gap, gap))
+        starts.append(st)
+    return reads, starts
+
+
+@pytest.mark.parametrize('wordlen,g_max', [(8, .2), (10, .15), (6, .2)])
+def test_overlap_bands_vs_oracle(wordlen, g_max):
+    from biseqt_amd import synth
+    from biseqt_amd.overlap import overlap_bands
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO
+    A = Alphabet('ACGT')
+    rng = synth.rng_for(1000 + wordlen)
+    reads, starts = _reads(rng, 6000, 14, 1500, .04, .03)
+    reads.append(reads[0].copy())                          # an identical read: p clamps at 1 on many diagonals
+    reads.append(synth.rand_seqs(rng, 1, 700)[0])          # an unrelated, shorter read
+    reads.append(np.resize(np.array([0, 1], np.uint8), 400))   # low complexity
+    pairs = list(itertools.combinations(range(len(reads)), 2))
+    stats = {}
+    got = overlap_bands(reads, pairs, wordlen, A, g_max, .99, stats=stats)
+    assert stats['fallback_pairs'] < len(pairs) // 2
+    nz = 0
+    for (i, j), g in zip(pairs, got):
+        if len(reads[i]) == len(reads[j]) and (reads[i] == reads[j]).all():
+            # documented divergence: the reference turns a pair of identical reads into a SELF comparison
+            # (seeds.py:33) and drops the main diagonal; the batch scores them as two different sequences
+            assert g['d_band'][0] <= 0 <= g['d_band'][1] and g['p'] > .95
+            continue
+        e = BO.highest_scoring_overlap_band(reads[i].tolist(), reads[j].tolist(), wordlen, 4, g_max, .99)
+        assert (g is None) == (e is None), (i, j)
+        if e is None:
+            continue
+        assert g['d_band'] == e['d_band'] and g['len'] == e['len'], (i, j, g, e)
+        assert g['p'] == e['p'] and g['score'] == e['score'], (i, j, g, e)
+        nz += g['p'] > .8
+    assert nz >= 5
+
+
+def test_config4_flow_bands_then_banded_overlap_alignment(oracle):
+    from biseqt_amd import synth
+    from biseqt_amd.overlap import overlap_alignments, overlap_bands
+    from biseqt_amd.sequence import Alphabet
+    A = Alphabet('ACGT')
+    rng = synth.rng_for(4)
+    reads, starts = _reads(rng, 20000, 24, 5000, .02, .02)
+    pairs = list(itertools.combinations(range(len(reads)), 2))
+    bands = overlap_bands(reads, pairs, 10, A, .2, .99)
+    alns = overlap_alignments(reads, pairs, bands, A, p_min=.8)
+    true_overlap = lambda i, j: min(starts[i], starts[j]) + 5000 - max(starts[i], starts[j])
+    found = 0
+    for (i, j), band, aln in zip(pairs, bands, alns):
+        if true_overlap(i, j) > 800:
+            assert band is not None and band['p'] > .8, (i, j, true_overlap(i, j), band)
+            assert band['d_band'][0] <= starts[j] - starts[i] <= band['d_band'][1]
+            assert aln is not None
+            r = oracle.solve(reads[i], reads[j], L=4, mode=1, alntype=2, diag_range=aln['diag_range'],
+                             match=1, mismatch=-3, go=-5, ge=-2)
+            assert aln['score'] == r['score'] and aln['transcript'] == r['transcript']
+            assert (aln['origin_start'], aln['mutant_start']) == (r['origin_idx'], r['mutant_idx'])
+            assert aln['score'] > 0.3 * true_overlap(i, j)
+            found += 1
+        elif true_overlap(i, j) < -200:
+            assert band is None or band['p'] < .8
+    assert found >= 5
