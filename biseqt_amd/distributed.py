@@ -60,6 +60,37 @@ def gather_records(local_records, n_total, rank, world, owner_of=None, device=No
     return full
 
 
+def gather_struct(local_records, n_total, rank, world, owner_of=None, device=None, group=None):
+    """:func:`gather_records` for any fixed-size record type (e.g. the 64-byte overlap-band records of
+    ``include/pw_overlap.h``): ``local_records`` is a numpy structured array; returns, on rank 0, the ``n_total``
+    records in global order, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    dt = local_records.dtype
+    size = dt.itemsize
+    if owner_of is None:
+        def owner_of(r):
+            return np.arange(r, n_total, world)
+    counts = [len(owner_of(r)) for r in range(world)]
+    cap = max(counts + [1])
+    t = torch.from_numpy(np.ascontiguousarray(local_records).view(np.uint8).reshape(-1).copy())
+    if device is not None:
+        t = t.to(device)
+    pad = torch.zeros(cap * size, dtype=torch.uint8, device=t.device)
+    pad[:t.numel()] = t
+    if world == 1:
+        chunks = [pad]
+    else:
+        chunks = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+        dist.gather(pad, chunks, dst=0, group=group)
+    if rank != 0:
+        return None
+    full = np.zeros(n_total, dt)
+    for r in range(world):
+        full[owner_of(r)] = chunks[r].cpu().numpy()[:counts[r] * size].view(dt)
+    return full
+
+
 def gather_bytes(local_bytes, rank, world, group=None):
     """Gather one ragged uint8 tensor per rank to rank 0 (transcripts): sizes first, then padded
     payloads.  Returns the list of per-rank tensors on rank 0, None elsewhere."""

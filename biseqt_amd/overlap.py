@@ -135,3 +135,14 @@ def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, **alig
         out[q] = dict(score=float(res['score'][k]), transcript=txs[k], origin_start=int(res['origin_idx'][k]),
                       mutant_start=int(res['mutant_idx'][k]), diag_range=dr[k])
     return out
+
+
+def raw_bands_sharded(reads, pairs, wordlen, alphabet_len, g_max, sensitivity, rank, world, device=None, gather_device=None):
+    """Config 4 across GPUs: pair q is scored by rank ``q mod world`` (no data-path collective), the 64-byte band
+    records are gathered to rank 0 in pair order (``torch.distributed``: RCCL on GPUs).  Returns the full record
+    array on rank 0, None elsewhere."""
+    from .distributed import gather_struct, shard_indices
+    mine = shard_indices(len(pairs), rank, world)
+    recs, _ = raw_bands(reads, [pairs[q] for q in mine], wordlen, alphabet_len, g_max, sensitivity,
+                        device=rank if device is None else device)
+    return gather_struct(recs, len(pairs), rank, world, device=gather_device)

@@ -78,3 +78,34 @@ def test_two_rank_gloo_gather(tmp_path, oracle):
         txcat[p % world] += r['transcript']
     got = open(os.path.join(str(tmp_path), 'tx.txt')).read().split('\n')
     assert got == [txcat[0], txcat[1]]
+
+
+def _worker_struct(rank, world, port, n_total, outdir):
+    import torch.distributed as dist
+    from biseqt_amd.distributed import gather_struct, shard_indices
+    from biseqt_amd.overlap import BAND_DTYPE
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = shard_indices(n_total, rank, world)
+    recs = np.zeros(len(mine), BAND_DTYPE)
+    recs['d_best'] = mine * 3 - 7                      # a value that identifies the global pair index
+    recs['w_best'] = mine / 8.0
+    recs['n_seeds'] = mine + 1
+    full = gather_struct(recs, n_total, rank, world)
+    if rank == 0:
+        np.save(os.path.join(outdir, 'bands.npy'), full)
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_of_overlap_band_records(tmp_path):
+    """The config-4 shard: pair q on rank q mod 2, 64-byte band records gathered to rank 0 in pair order."""
+    import torch.multiprocessing as mp
+    n_total, world = 11, 2
+    mp.spawn(_worker_struct, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    full = np.load(os.path.join(str(tmp_path), 'bands.npy'))
+    q = np.arange(n_total)
+    assert (full['d_best'] == q * 3 - 7).all() and (full['w_best'] == q / 8.0).all() and (full['n_seeds'] == q + 1).all()
