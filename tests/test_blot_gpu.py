@@ -121,3 +121,16 @@ def test_local_similarity_vs_oracle(wordlen, K, n):
     assert any(h['segment'][0][0] < 10 and h['segment'][0][1] > -10 and h['segment'][1][0] < K
                and 0.8 * p_match <= h['p'] <= 1.2 * p_match for h in homs)
     wb.close()
+
+
+def test_adversarial_fuzz_of_seeds_bands_segments():
+    """A bounded run of tests/micro/fuzz_seeds_gpu.py (3366 cases clean in the 2-minute run recorded in DESIGN.md):
+    rows and their order, band counts, the best overlap band (single-pair and batched paths), similar segments --
+    repeats, two-letter sequences, shared blocks on several diagonals, all against the oracles."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('fuzz_seeds_gpu', os.path.join(os.path.dirname(__file__), 'micro', 'fuzz_seeds_gpu.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    n, bad = fz.run(12, 20261004)
+    assert bad == 0 and n > 50
