@@ -188,6 +188,9 @@ def main():
         done_cells += step(i)
     fence()
     elapsed = time.perf_counter() - t0
+    # fill-kernel duration of the LAST timed step of each batch (HIP events on its stream): with two batches in flight
+    # the two fills co-run, so each takes about twice as long as alone while two complete per that time
+    overlapped_ms = [b.fill_ms() for b in batches[:min(nfl, args.steps)]]
     # per-kernel durations (HIP events recorded by the library on the launch stream): sample a few extra steps of
     # ONE batch alone, outside the timed region, so that the kernel time is not stretched by the other batch
     stream = streams[0].cuda_stream
@@ -232,7 +235,9 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(batch.kernel_name, n_local),
                          'kernel': batch.kernel_name,
-                         'kernel_ms': round(fill, 4), 'algorithmic_bytes_per_launch': int(alg_bytes),
+                         'kernel_ms': round(fill, 4), 'kernel_ms_note': 'one batch running alone (5 extra steps after the '
+                         'timed region); in the timed region %d fills co-run, each lasting %s ms' % (nfl, '/'.join('%.2f' % v for v in overlapped_ms)),
+                         'algorithmic_bytes_per_launch': int(alg_bytes),
                          'kernel_gcups': round(cells / (fill * 1e-3) / 1e9, 2),
                          'traceback_kernel_ms': round(float(np.mean(trace_ms)), 4)},
             'results_ok': ok,
