@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
   __syncthreads();
   // ---- pass 2: how many occupied diagonals could reach the same p ----
   int ties = 0;
-  const double thr = wbest >= 1.0 ? 1.0 : wbest - fabs(wbest) * 1e-9;
+  const double wcap = wbest >= 1.0 ? 1.0 : wbest;           // p = min(w^(1/k), 1): everything at or above 1 ties
+  const double thr = wcap - fabs(wcap) * 1e-9;
   for (int dd = b; dd < e; dd++) {
     if (pre(dd) == pre(dd - 1)) continue;
     int n, L, r;
