@@ -99,6 +99,11 @@ class WordBlot(SeedIndex):
         super(WordBlot, self).__init__(S, T, **kw)
         self._graph_key = None
 
+    def _presentation(self):
+        """Order in which the class iterates its seeds, as indices into the table rows (None = table order).  The
+        in-memory *Ref variants scan T left to right instead (``blot.py:607-620``)."""
+        return None
+
     def score_num_seeds(self, **kw):
         """z-scores of an observed number of seeds in a region against H0 and H1 (``blot.py:238-271``)."""
         num_seeds, area = kw['num_seeds'], kw['area']
@@ -155,15 +160,21 @@ class WordBlot(SeedIndex):
         return np.minimum(p, 1), d_radius, a_radius
 
     def score_seeds(self, K):
-        """One dict per seed, in table order: ``seed`` (d, a), ``neighs`` (indices of the seeds in its
+        """One dict per seed, in the class's seed order: ``seed`` (d, a), ``neighs`` (indices of the seeds in its
         neighbourhood), ``p`` estimated match probability of a segment centred there (``blot.py:376-408``)."""
         rows = self.rows()
         if not len(rows):
             return []
         p, _, _ = self._seed_ps(K)
         off, adj = self._idx.graph_fetch()
-        return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'neighs': adj[off[k]:off[k + 1]].tolist(), 'p': p[k]}
-                for k in range(len(rows))]
+        perm = self._presentation()
+        if perm is None:
+            return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'neighs': adj[off[k]:off[k + 1]].tolist(), 'p': p[k]}
+                    for k in range(len(rows))]
+        inv = np.empty(len(perm), np.int64)
+        inv[perm] = np.arange(len(perm))
+        return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'neighs': inv[adj[off[k]:off[k + 1]]].tolist(), 'p': p[k]}
+                for k in perm.tolist()]
 
     def similar_segments(self, K_min, p_min, at_least_one=False):
         """All maximal local similarities of a minimum length and match probability (``blot.py:410-490``): seeds
@@ -175,14 +186,21 @@ class WordBlot(SeedIndex):
             assert not at_least_one, 'no seeds found while at_least_one=True'
             return
         p, d_radius, a_radius = self._seed_ps(K_min)
+        perm = self._presentation()
+        if perm is None:
+            rank = np.arange(len(rows))                  # position of every table row in the class's seed order
+        else:
+            rank = np.empty(len(perm), np.int64)
+            rank[perm] = np.arange(len(perm))
         avail = p >= p_min
         if not avail.any() and at_least_one:
-            avail[int(np.argmax(p))] = True
+            cand = np.flatnonzero(p == p.max())
+            avail[cand[np.argmin(rank[cand])]] = True    # np.argmax over the class's list: its first maximum
         if not avail.any():
             return
         labels = self._idx.graph_components(avail)
         idx = np.flatnonzero(labels >= 0)
-        order = idx[np.argsort(labels[idx], kind='stable')]
+        order = idx[np.lexsort((rank[idx], labels[idx]))]       # grouped by component, seed order inside
         lab = labels[order]
         starts = np.flatnonzero(np.r_[True, lab[1:] != lab[:-1]])
         d, a = rows[order, 0].astype(np.int64), rows[order, 1].astype(np.int64)
@@ -193,8 +211,9 @@ class WordBlot(SeedIndex):
         a_hi = np.maximum.reduceat(a, starts) + a_radius
         psum = np.add.reduceat(p[order], starts)
         cnt = np.diff(np.r_[starts, len(order)])
-        for s in range(len(starts)):
-            first = int(lab[starts[s]])              # the seed the search starts from is counted twice (:449,455)
+        firsts = order[starts]                                   # the seed each search starts from
+        for s in np.argsort(rank[firsts], kind='stable').tolist():
+            first = int(firsts[s])                       # ... and it is counted twice (:449,455)
             d_min = min(lenS, max(int(d_lo[s]), -lenT))
             d_max = min(lenS, max(int(d_hi[s]), -lenT))
             a_min = max(int(a_lo[s]), 0)
@@ -248,8 +267,10 @@ class WordBlotOverlap(WordBlot):
         p = np.zeros(len(rows))
         p[pos] = np.exp(np.log(word_p[pos]) / self.wordlen)
         p = np.minimum(p, 1)
+        perm = self._presentation()
+        ks = range(len(rows)) if perm is None else perm.tolist()
         return [{'seed': (int(rows[k, 0]), int(rows[k, 1])), 'r': np.float64(rad[k]), 'L': int(L[k]), 'p': p[k]}
-                for k in range(len(rows))]
+                for k in ks]
 
     def highest_scoring_overlap_band(self):
         """The diagonal band with the highest estimated match probability: ``d_band``, ``p``, ``len``, ``score``
@@ -267,3 +288,84 @@ class WordBlotOverlap(WordBlot):
         num_seeds = self.seed_count(d_band=d_band)
         res['score'] = (num_seeds - mu_H1) / sd_H1
         return res
+
+
+def _check_ref_memory(alphabet, wordlen, allowed_memory):
+    """The in-memory variants refuse word lengths whose k-mer table would not fit the allowed memory
+    (``blot.py:596-604``: one python int -- 24 bytes under python 2 -- per possible k-mer)."""
+    num_kmers = len(alphabet) ** wordlen
+    mem_needed_gb = np.power(2, np.log2(24. * num_kmers) - 30)
+    assert allowed_memory > 0, 'allowed memory must be positive'
+    if mem_needed_gb > allowed_memory:
+        raise MemoryError('not enough memory (max = %.2f GB) to store %d-mers (%.2f GB needed)'
+                          % (allowed_memory, wordlen, mem_needed_gb))
+
+
+class _RefMixin(object):
+    """Shared behaviour of the reference's in-memory classes: built around ONE sequence (``ref``), every query
+    names the other one, and seeds are iterated with T scanned left to right, hits of S ascending
+    (``blot.py:607-620``) -- i.e. the table rows ordered by (j, i)."""
+
+    def _init_ref(self, ref, allowed_memory, kw):
+        self._ref_kw = dict(kw)
+        self.allowed_memory = allowed_memory
+        _check_ref_memory(kw['alphabet'], kw['wordlen'], allowed_memory)
+        self.wordlen, self.alphabet = kw['wordlen'], kw['alphabet']
+        self.g_max, self.sensitivity = kw['g_max'], kw['sensitivity']
+        self.S, self.T = ref, None
+        self._idx = None
+
+    def _set_query(self, seq):
+        if self.T is not None and self.T == seq and self._idx is not None:
+            return
+        if self._idx is not None:
+            self._idx.close()
+        kw = dict(self._ref_kw)
+        g_max, sensitivity = kw.pop('g_max'), kw.pop('sensitivity')
+        self._base.__init__(self, self.S, seq, g_max=g_max, sensitivity=sensitivity, **kw)
+        self._perm = None
+
+    def _presentation(self):
+        if self._perm is None:
+            rows = self.rows().astype(np.int64)
+            i, j = (rows[:, 1] + rows[:, 0]) // 2, (rows[:, 1] - rows[:, 0]) // 2
+            self._perm = np.lexsort((i, j))
+        return self._perm
+
+    def seeds(self, exclude_trivial=True):
+        assert self.T is not None
+        rows = self.rows().astype(np.int64)[self._presentation()]
+        return list(zip(((rows[:, 1] + rows[:, 0]) // 2).tolist(), ((rows[:, 1] - rows[:, 0]) // 2).tolist()))
+
+
+class WordBlotLocalRef(_RefMixin, WordBlot):
+    """In-memory variant of :class:`WordBlot` (``blot.py:626-700``): ``WordBlotLocalRef(ref, allowed_memory=1, **kw)``,
+    then ``similar_segments(seq, K_min, p_min)`` / ``score_seeds_(seq, K)`` for any number of query sequences."""
+    _base = WordBlot
+
+    def __init__(self, ref, allowed_memory=1, **kw):
+        self._init_ref(ref, allowed_memory, kw)
+
+    def score_seeds_(self, seq, K):
+        self._set_query(seq)
+        return WordBlot.score_seeds(self, K)
+
+    def similar_segments(self, seq, K_min, p_min, at_least_one=False):
+        self._set_query(seq)
+        return WordBlot.similar_segments(self, K_min, p_min, at_least_one=at_least_one)
+
+
+class WordBlotOverlapRef(_RefMixin, WordBlotOverlap):
+    """In-memory variant of :class:`WordBlotOverlap` (``blot.py:582-624``)."""
+    _base = WordBlotOverlap
+
+    def __init__(self, ref, allowed_memory=1, **kw):
+        self._init_ref(ref, allowed_memory, kw)
+
+    def score_seeds_(self, seq):
+        self._set_query(seq)
+        return WordBlotOverlap.score_seeds(self)
+
+    def highest_scoring_overlap_band(self, seq):
+        self._set_query(seq)
+        return WordBlotOverlap.highest_scoring_overlap_band(self)

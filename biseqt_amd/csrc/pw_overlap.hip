@@ -97,7 +97,7 @@ __device__ __forceinline__ double ov_x(int d, int ls, int lt, BandConst c) {
 }
 
 // one workgroup per pair
-__global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* __restrict__ hist,
+__global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* hist,
                                                      const unsigned long long* __restrict__ nrows, const uint32_t* __restrict__ first_e,
                                                      const uint64_t* __restrict__ ks, const uint32_t* __restrict__ ps,
                                                      const uint64_t* __restrict__ kt, const uint32_t* __restrict__ pt, int64_t nt,
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
   const int p = (int)blockIdx.x, tid = (int)threadIdx.x;
   const DPair pr = pairs[p];
   const int ls = pr.s_len, lt = pr.t_len, nd = ls + lt + 1;
-  uint32_t* __restrict__ h = hist + pr.hbase;          // index dd = d + lt
+  uint32_t* h = hist + pr.hbase;                       // index dd = d + lt (written and re-read across the workgroup)
   pw_overlap_band o;
   memset(&o, 0, sizeof o);
   o.n_seeds = (int64_t)nrows[p];

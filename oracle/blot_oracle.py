@@ -101,9 +101,18 @@ def match_p(n, d_radius, L, alphabet_len, wordlen):
     return min(p, 1)
 
 
-def score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=()):
+def _seed_list(S, T, wordlen, alphabet_len, mask, order):
+    """(i, j) seeds in the order the class iterates them: 'table' = SeedIndex.seeds(exclude_trivial=True)
+    (seeds.py:164-197), 'mutant' = the in-memory *Ref classes (blot.py:607-620: T scanned left to right)."""
+    if order == 'mutant':
+        assert not mask
+        return SO.seeds_by_mutant(S, T, wordlen, alphabet_len, exclude_trivial=True)
     rows, self_comp = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
-    ij = SO.seeds(rows, self_comp, exclude_trivial=True)
+    return SO.seeds(rows, self_comp, exclude_trivial=True)
+
+
+def score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=(), order='table'):
+    ij = _seed_list(S, T, wordlen, alphabet_len, mask, order)
     all_seeds = [SO.to_diagonal_coordinates(i, j) for i, j in ij]
     if not all_seeds:
         return []
@@ -127,8 +136,8 @@ def score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=()):
     return out
 
 
-def highest_scoring_overlap_band(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=()):
-    scored = score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask)
+def highest_scoring_overlap_band(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=(), order='table'):
+    scored = score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask, order)
     if not scored:
         return None
     idx = max(range(len(scored)), key=lambda i: scored[i]['p'])
@@ -184,9 +193,8 @@ def find_all_neighbors(all_seeds, d_radius, a_radius):                          
     return list(zip(all_seeds, neighs))
 
 
-def score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K, mask=()):   # blot.py:376-408
-    rows, self_comp = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
-    ij = SO.seeds(rows, self_comp, exclude_trivial=True)
+def score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K, mask=(), order='table'):   # blot.py:376-408
+    ij = _seed_list(S, T, wordlen, alphabet_len, mask, order)
     all_seeds = [SO.to_diagonal_coordinates(i, j) for i, j in ij]
     d_radius = int(np.ceil(band_radius(K, g_max, sensitivity)))
     a_radius = K
@@ -198,13 +206,14 @@ def score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K, mask=(
     return out
 
 
-def similar_segments(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, p_min, at_least_one=False, mask=()):
+def similar_segments(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, p_min, at_least_one=False, mask=(),
+                     order='table'):
     """blot.py:410-490, the depth-first growth included (the order of `ps_in_seg`, and with it the last bits of the
     averaged p, follows the KD-tree's neighbour order)."""
     rows, _ = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
     d_radius = int(np.ceil(band_radius(K_min, g_max, sensitivity)))
     a_radius = K_min
-    scored = score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, mask)
+    scored = score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, mask, order)
     lenS, lenT = len(S), len(T)
     avail = [rec['p'] >= p_min for rec in scored]
     if not any(avail) and at_least_one:

@@ -134,3 +134,46 @@ def test_adversarial_fuzz_of_seeds_bands_segments():
     spec.loader.exec_module(fz)
     n, bad = fz.run(12, 20261004)
     assert bad == 0 and n > 50
+
+
+@pytest.mark.parametrize('wordlen', [8, 10])
+def test_in_memory_ref_variants(wordlen):
+    """WordBlotLocalRef / WordBlotOverlapRef (blot.py:582-700): one reference sequence, many queries, seeds iterated
+    with T scanned left to right -- against the oracle in that order; and the MemoryError of long words
+    (tests/test_blot.py:134-136, 175-177)."""
+    from biseqt_amd import synth
+    from biseqt_amd.blot import WordBlotLocalRef, WordBlotOverlapRef
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO, seeds_oracle as SO
+    A = Alphabet('ACGT')
+    kw = dict(g_max=.2, sensitivity=.99, alphabet=A, wordlen=wordlen)
+    rng = synth.rng_for(wordlen)
+    n, K = 2000, 500
+    hom = synth.rand_seqs(rng, 1, K)[0]
+    s = np.concatenate([synth.rand_seqs(rng, 1, n - K)[0], hom])
+    queries = [np.concatenate([synth.mutate(rng, hom, .05, .05, .05), synth.rand_seqs(rng, 1, n - K)[0]]),
+               np.concatenate([synth.rand_seqs(rng, 1, 700)[0], synth.mutate(rng, s[300:900], .03, .02, .2)]),
+               synth.rand_seqs(rng, 1, 500)[0]]
+    with pytest.raises(MemoryError):
+        WordBlotLocalRef(_mk(A, s), allowed_memory=1, **dict(kw, wordlen=15))
+    with pytest.raises(MemoryError):
+        WordBlotOverlapRef(_mk(A, s), allowed_memory=1, **dict(kw, wordlen=15))
+    loc = WordBlotLocalRef(_mk(A, s), allowed_memory=1, **kw)
+    ovl = WordBlotOverlapRef(_mk(A, s), allowed_memory=1, **kw)
+    for t in queries:
+        T = _mk(A, t)
+        got = list(loc.similar_segments(T, 300, .7))
+        exp = BO.similar_segments(s.tolist(), t.tolist(), wordlen, 4, .2, .99, 300, .7, order='mutant')
+        assert [g['segment'] for g in got] == [e['segment'] for e in exp]
+        for g, e in zip(got, exp):
+            assert abs(g['p'] - e['p']) <= 1e-12 * max(abs(e['p']), 1e-300)
+        assert loc.seeds() == SO.seeds_by_mutant(s.tolist(), t.tolist(), wordlen, 4)
+        sc = loc.score_seeds_(T, 300)
+        ex = BO.score_seeds_local(s.tolist(), t.tolist(), wordlen, 4, .2, .99, 300, order='mutant')
+        assert [(x['seed'], x['p'], sorted(x['neighs'])) for x in sc] == [(x['seed'], x['p'], sorted(x['neighs'])) for x in ex]
+        rec = ovl.highest_scoring_overlap_band(T)
+        ref = BO.highest_scoring_overlap_band(s.tolist(), t.tolist(), wordlen, 4, .2, .99, order='mutant')
+        assert (rec is None) == (ref is None)
+        if rec is not None:
+            assert rec['d_band'] == ref['d_band'] and rec['p'] == ref['p'] and rec['score'] == ref['score']
+    loc.close(); ovl.close()
