@@ -118,7 +118,7 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_batch_arena_device', 'pw_batch_solve', 'pw_batch_traceback',
            'pw_batch_traceback_from', 'pw_batch_sync', 'pw_batch_results_device',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
-           'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_fill_ms',
+           'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_table', 'pw_batch_fill_ms',
            'pw_batch_trace_ms']
 # every symbol include/pw_seeds.h declares
 SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_seeds_is_self', 'pw_seeds_rows_device',
@@ -195,6 +195,7 @@ def load():
     lib.pw_batch_results.argtypes = [C.c_void_p, C.c_void_p]
     lib.pw_batch_transcripts.argtypes = [C.c_void_p, C.c_void_p]
     lib.pw_batch_scores.argtypes = [C.c_void_p, C.c_int32, P(C.c_double), C.c_int64]
+    lib.pw_batch_table.argtypes = [C.c_void_p, C.c_int32, P(C.c_double), C.c_int64]
     lib.pw_batch_fill_ms.argtypes = [C.c_void_p]
     lib.pw_batch_fill_ms.restype = C.c_float
     lib.pw_batch_trace_ms.argtypes = [C.c_void_p]

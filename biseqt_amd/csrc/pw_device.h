@@ -295,8 +295,10 @@ hipError_t launch_tile_finish_T(const FillParams<T>& a, int pair, hipStream_t st
   return hipGetLastError();
 }
 
-// K2a: one WORKGROUP (up to 8 wavefronts, 2048 diagonals each) per pair for bands wider than 2048 diagonals.
-template <typename T, bool BANY, bool TRACK, bool GENERIC>
+// K2a: one WORKGROUP (up to 8 wavefronts, 64 * BK diagonals each) per pair: bands wider than 2048 diagonals
+// (BK = 32), and -- with BK = 4 / 8 / 16 -- the low-latency layout for batches of a few pairs, where spreading one
+// pair over 8 wavefronts beats one wavefront working through 16 or 32 diagonals per lane.
+template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
 __global__ __launch_bounds__(512) void k_fill_mw(const FillParams<T> a) {
   __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
   const T* tab = a.subst;
@@ -310,19 +312,19 @@ __global__ __launch_bounds__(512) void k_fill_mw(const FillParams<T> a) {
   const int slot = (int)blockIdx.x;
   const int pair = a.order ? a.order[slot] : slot;
   const PairDesc pd = a.pairs[pair];
-  WaveFill<DevPM, T, 32, BANY, TRACK, GENERIC> w(a, pd, tab);
+  WaveFill<DevPM, T, BK, BANY, TRACK, GENERIC> w(a, pd, tab);
   w.pair_slot = pair;
   w.run();
 }
 
-template <typename T>
+template <typename T, int BK>
 hipError_t launch_variant_mw(const FillParams<T>& a, int variant, int nw, int nblocks, hipStream_t st) {
   const dim3 grid((unsigned)nblocks), block((unsigned)(64 * nw));
   switch (variant) {
-    case VAR_FAST_ANY_TRACK: hipLaunchKernelGGL((k_fill_mw<T, true, true, false>), grid, block, 0, st, a); break;
-    case VAR_FAST_TRACK: hipLaunchKernelGGL((k_fill_mw<T, false, true, false>), grid, block, 0, st, a); break;
-    case VAR_FAST: hipLaunchKernelGGL((k_fill_mw<T, false, false, false>), grid, block, 0, st, a); break;
-    case VAR_GENERIC: hipLaunchKernelGGL((k_fill_mw<T, false, true, true>), grid, block, 0, st, a); break;
+    case VAR_FAST_ANY_TRACK: hipLaunchKernelGGL((k_fill_mw<T, BK, true, true, false>), grid, block, 0, st, a); break;
+    case VAR_FAST_TRACK: hipLaunchKernelGGL((k_fill_mw<T, BK, false, true, false>), grid, block, 0, st, a); break;
+    case VAR_FAST: hipLaunchKernelGGL((k_fill_mw<T, BK, false, false, false>), grid, block, 0, st, a); break;
+    case VAR_GENERIC: hipLaunchKernelGGL((k_fill_mw<T, BK, false, true, true>), grid, block, 0, st, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

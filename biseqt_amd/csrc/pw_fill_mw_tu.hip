@@ -6,7 +6,13 @@
 #define PW_CAT(a, b) PW_CAT2(a, b)
 
 namespace pw {
-hipError_t PW_CAT(launch_fill_mw_, PW_TNAME)(const FillParams<PW_T>& a, int variant, int nw, int nblocks, hipStream_t st) {
-  return launch_variant_mw<PW_T>(a, variant, nw, nblocks, st);
+hipError_t PW_CAT(launch_fill_mw_, PW_TNAME)(const FillParams<PW_T>& a, int variant, int bk, int nw, int nblocks, hipStream_t st) {
+  switch (bk) {
+    case 4: return launch_variant_mw<PW_T, 4>(a, variant, nw, nblocks, st);
+    case 8: return launch_variant_mw<PW_T, 8>(a, variant, nw, nblocks, st);
+    case 16: return launch_variant_mw<PW_T, 16>(a, variant, nw, nblocks, st);
+    case 32: return launch_variant_mw<PW_T, 32>(a, variant, nw, nblocks, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 }  // namespace pw

@@ -27,8 +27,8 @@ static const int kNumPackedBK = 8;
 hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st);
 // wide bands: one workgroup of nw wavefronts (2048 diagonals each, nw <= kMaxWavesPerPair) per pair
 static const int kMaxWavesPerPair = 8;
-hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st);
-hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int nw, int nblocks, hipStream_t st);
+hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int bk, int nw, int nblocks, hipStream_t st);
+hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int bk, int nw, int nblocks, hipStream_t st);
 // tiled single-pair kernel (K2b): tiles of kTileCentralDiags diagonals + ghosts, time blocks of kTileBlocks blocks
 // (geometry overridable at build time for tuning runs: -DPW_TILE_LANES= -DPW_TILE_BK= -DPW_TILE_GHOST= -DPW_TILE_BLOCKS=)
 #ifndef PW_TILE_LANES
@@ -49,6 +49,7 @@ hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int n
 hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st);
 hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
+hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double* out, hipStream_t st);
 
 }  // namespace pw
 #endif

@@ -44,6 +44,23 @@ __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
   }
 }
 
+// Standard-mode score plane [d - dmin][a] -> the reference's row-major table [x][y] as doubles (what the drop-in
+// materialises for Aligner.table_scores, pw.py:278-285): coalesced writes, the strided reads stay on the device.
+template <typename T>
+__global__ __launch_bounds__(256) void k_table_rowmajor(const T* __restrict__ plane, int X, int Y, int pitch, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= (int64_t)(X + 1) * (Y + 1)) return;
+  const int x = (int)(c / (Y + 1)), y = (int)(c - (int64_t)x * (Y + 1));
+  out[c] = (double)plane[(int64_t)(x - y + Y) * pitch + (x < y ? x : y)];
+}
+hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double* out, hipStream_t st) {
+  const int64_t n = (int64_t)(X + 1) * (Y + 1);
+  const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+  if (f64) hipLaunchKernelGGL((k_table_rowmajor<double>), grid, blk, 0, st, (const double*)plane, X, Y, pitch, out);
+  else hipLaunchKernelGGL((k_table_rowmajor<int32_t>), grid, blk, 0, st, (const int32_t*)plane, X, Y, pitch, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
   if (p.npairs <= 0) return hipSuccess;
   static int walkers = 0;
@@ -81,13 +98,13 @@ hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int n
 hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st) { return launch_tile_finish_i32(a, pair, st); }
 hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st) { return launch_tile_finish_f64(a, pair, st); }
 
-hipError_t launch_fill_mw_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
-hipError_t launch_fill_mw_f64(const FillParams<double>&, int, int, int, hipStream_t);
-hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int nw, int nblocks, hipStream_t st) {
-  return launch_fill_mw_i32(a, variant, nw, nblocks, st);
+hipError_t launch_fill_mw_i32(const FillParams<int32_t>&, int, int, int, int, hipStream_t);
+hipError_t launch_fill_mw_f64(const FillParams<double>&, int, int, int, int, hipStream_t);
+hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int bk, int nw, int nblocks, hipStream_t st) {
+  return launch_fill_mw_i32(a, variant, bk, nw, nblocks, st);
 }
-hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int nw, int nblocks, hipStream_t st) {
-  return launch_fill_mw_f64(a, variant, nw, nblocks, st);
+hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int bk, int nw, int nblocks, hipStream_t st) {
+  return launch_fill_mw_f64(a, variant, bk, nw, nblocks, st);
 }
 
 hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st) {

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/pw_batch.h"
@@ -27,6 +28,7 @@ static_assert(sizeof(pw::Result) == 32 && sizeof(pw_result) == 32, "result recor
 static_assert(sizeof(pw::PairDesc) == 96, "PairDesc layout");
 
 namespace {
+int env_int(const char* name, int dflt);
 
 thread_local std::string g_err;
 
@@ -194,6 +196,10 @@ int batch_build(pw_batch* b) {
     else if (bk1) { pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 0; }
     if (pbk) b->variant = pw::VAR_FAST16;
   }
+  // latency mode: with at most kLatencyPairs pairs the batch is a few wavefronts on a 1024-SIMD chip, so the time is
+  // the length of one pair's dependency chain, not throughput (PWLIB_LATENCY_MODE=0 / 1 overrides)
+  const int lat_env = env_int("PWLIB_LATENCY_MODE", -1);
+  const bool latency_mode = lat_env >= 0 ? lat_env != 0 : nsolv <= 64;
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {
     pw::PairDesc& d = b->descs[k];
@@ -214,6 +220,14 @@ int batch_build(pw_batch* b) {
         // wider than one wavefront holds: a workgroup of nw wavefronts, 2048 diagonals each
         bk = 32;
         nw = (d.ndiag + 2047) / 2048;
+        nl = 64 * nw;
+      } else if (latency_mode && bk >= 16) {
+        // a handful of pairs cannot fill the chip anyway: spread each over up to 8 wavefronts with few diagonals
+        // per lane (the step count is fixed by X + Y; the work per step shrinks 4-8x, the exchange costs ~0.3 us)
+        for (int cand : {4, 8, 16}) {
+          if ((int64_t)64 * pw::kMaxWavesPerPair * cand >= d.ndiag) { bk = cand; break; }
+        }
+        nw = (d.ndiag + 64 * bk - 1) / (64 * bk);
         nl = 64 * nw;
       }
     }
@@ -308,7 +322,7 @@ int launch_all_fills(pw_batch* b, hipStream_t st) {
   a.go = (T)b->go; a.ge = (T)b->ge;
   for (auto& c : b->classes) {
     a.order = c.d_order;
-    if (c.nw > 1) HIP_TRY(pw::launch_fill_mw(a, b->variant, c.nw, (int)c.order.size(), st));
+    if (c.nw > 1) HIP_TRY(pw::launch_fill_mw(a, b->variant, c.bk, c.nw, (int)c.order.size(), st));
     else HIP_TRY(pw::launch_fill(a, b->variant, c.bk, (int)c.order.size(), st));
   }
   // K2b: tiled pairs, one after another; per pair one launch per time block, then the end-cell search
@@ -394,10 +408,11 @@ int pw_batch_score_type(const pw_batch* b) { return b->use_f64 ? 1 : 0; }
 
 const char* pw_batch_kernel_name(const pw_batch* b) {
   static thread_local char name[96];
-  int bk = 0; size_t most = 0;
-  for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; }
+  int bk = 0, nw = 1; size_t most = 0;
+  for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; nw = c.nw; }
   if (b->classes.empty() && !b->tiled.empty()) { snprintf(name, sizeof name, "k_fill_tile<%s> x time blocks", b->use_f64 ? "double" : "int"); return name; }
   const char* t = b->use_f64 ? "double" : "int";
+  if (nw > 1) { snprintf(name, sizeof name, "k_fill_mw<%s, %d, ...> x %d wavefronts", t, bk, nw); return name; }
   switch (b->variant) {
     case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false"); break;
     case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;
@@ -507,6 +522,23 @@ int pw_batch_scores(pw_batch* b, int32_t k, double* out, int64_t n) {
     HIP_TRY(hipMemcpy(tmp.data(), (int32_t*)b->d_hdump + d.h_off, 4 * (size_t)want, hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < want; i++) out[i] = (double)tmp[(size_t)i];
   }
+  return 0;
+}
+
+int pw_batch_table(pw_batch* b, int32_t k, double* out, int64_t n) {
+  if (!(b->flags & PW_FLAG_DUMP_SCORES) || k < 0 || k >= b->n || !b->descs[k].solvable) return fail("no score plane");
+  if (b->mode != pw::STD_MODE) return fail("pw_batch_table: standard mode only");
+  const pw::PairDesc& d = b->descs[k];
+  const int64_t want = (int64_t)(d.X + 1) * (d.Y + 1);
+  if (n < want) return fail("table buffer too small");
+  HIP_TRY(hipSetDevice(b->device));
+  double* dev = nullptr;
+  HIP_TRY(hipMalloc((void**)&dev, 8 * (size_t)want));
+  const void* plane = b->use_f64 ? (const void*)((double*)b->d_hdump + d.h_off) : (const void*)((int32_t*)b->d_hdump + d.h_off);
+  hipError_t e = pw::launch_table_rowmajor(plane, b->use_f64, d.X, d.Y, d.h_pitch, dev, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, dev, 8 * (size_t)want, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(hipGetErrorString(e));
   return 0;
 }
 
@@ -667,6 +699,9 @@ intpair dptable_solve(dptable* T) {
   pr.origin_off = 0; pr.mutant_off = (uint64_t)moff; pr.origin_len = X; pr.mutant_len = Y;
   pr.dmin = prob->mode == BANDED_MODE ? prob->banded_params->dmin : 0;
   pr.dmax = prob->mode == BANDED_MODE ? prob->banded_params->dmax : 0;
+  const bool timing = env_int("PWLIB_TIMING", 0) != 0;
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_a = now();
   // the full table (host: 48 B per cell) is materialised for tables up to 2^24 cells; beyond that only the
   // optimal cell is (table_scores-style callers need PWLIB_NO_TABLE unset and a table that size)
   const bool want_table = prob->mode == STD_MODE && !env_int("PWLIB_NO_TABLE", 0) && h->ncells <= (1 << 24);
@@ -679,22 +714,24 @@ intpair dptable_solve(dptable* T) {
     fprintf(stderr, "pwlib: %s\n", pw_last_error());
     return none;
   }
+  const double t_b = now();
+  double t_plane = 0.0;
   // ---- materialise what the reference's callers read out of C memory ----
   free(h->choice_slab); h->choice_slab = nullptr;
   if (want_table) {
-    // every cell's choices[0].score (Aligner.table_scores, pw.py:278-285)
-    const int pitch = std::min(X, Y) + 1;
-    std::vector<double> plane((size_t)(X + Y + 1) * pitch);
-    if (pw_batch_scores(h->batch, 0, plane.data(), (int64_t)plane.size()) != 0) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); return none; }
-    h->choice_slab = (alnchoice*)calloc((size_t)h->ncells, sizeof(alnchoice));
-    if (!h->choice_slab) { fprintf(stderr, "pwlib: out of memory\n"); return none; }
-    for (int x = 0; x <= X; x++) for (int y = 0; y <= Y; y++) {
-      const int64_t c = (int64_t)x * (Y + 1) + y;
+    // every cell's choices[0].score (Aligner.table_scores, pw.py:278-285): the table comes back row-major
+    double* table = (double*)malloc(sizeof(double) * (size_t)h->ncells);
+    h->choice_slab = (alnchoice*)malloc(sizeof(alnchoice) * (size_t)h->ncells);
+    if (!table || !h->choice_slab) { fprintf(stderr, "pwlib: out of memory\n"); free(table); return none; }
+    if (pw_batch_table(h->batch, 0, table, h->ncells) != 0) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); free(table); return none; }
+    t_plane = now() - t_b;
+    const int mins_cd = prob->max_new_mins;
+    for (int64_t c = 0; c < h->ncells; c++) {
       alnchoice* ch = &h->choice_slab[c];
-      ch->op = 0; ch->base = NULL; ch->mins_cd = prob->max_new_mins; ch->cur_min = 0;
-      ch->score = plane[(size_t)(x - y + Y) * pitch + (size_t)std::min(x, y)];
+      ch->op = 0; ch->score = table[c]; ch->base = NULL; ch->mins_cd = mins_cd; ch->cur_min = 0;
       h->cell_slab[c].num_choices = 1; h->cell_slab[c].choices = ch;
     }
+    free(table);
   } else if (res.opt_i >= 0 && res.opt_j >= 0) {
     if (h->lazy) {
       free(h->opt_row);
@@ -708,6 +745,7 @@ intpair dptable_solve(dptable* T) {
     T->cells[res.opt_i][res.opt_j].num_choices = 1;
     T->cells[res.opt_i][res.opt_j].choices = h->choice_slab;
   }
+  if (timing) fprintf(stderr, "pwlib timing: create+upload+solve+sync %.2f ms, materialise %.2f ms (score plane D2H %.2f ms)\n", t_b - t_a, now() - t_b, t_plane);
   intpair opt = {res.opt_i, res.opt_j};
   return opt;
 }

@@ -103,6 +103,9 @@ int pw_batch_results(pw_batch* b, pw_result* host_out);                         
 int pw_batch_transcripts(pw_batch* b, uint8_t* host_out);                        /* synchronous D2H of all slots */
 /* score plane of pair k (PW_FLAG_DUMP_SCORES): out[(d-dmin)*pitch + a], pitch = min(X,Y)+1, as doubles */
 int pw_batch_scores(pw_batch* b, int32_t k, double* host_out, int64_t n);
+/* Standard mode only: the same scores as the reference's table, host_out[x * (Y + 1) + y] for 0 <= x <= X,
+ * 0 <= y <= Y (n >= (X + 1)(Y + 1)); transposed on the device.  Needs PW_FLAG_DUMP_SCORES. */
+int pw_batch_table(pw_batch* b, int32_t k, double* host_out, int64_t n);
 
 /* mean duration (ms) of the fill kernel launches of the last pw_batch_solve (PW_FLAG_PROFILE), and
  * of the dominant launch alone; < 0 if unavailable.  Synchronises on the recorded events. */
