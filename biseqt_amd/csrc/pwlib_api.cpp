@@ -166,6 +166,10 @@ int batch_build(pw_batch* b) {
   else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
+  // latency mode: with at most 256 pairs the batch is a few hundred wavefronts on a 1024-SIMD chip, so the time is
+  // the length of one pair's dependency chain, not throughput (PWLIB_LATENCY_MODE=0 / 1 overrides)
+  const int lat_env = env_int("PWLIB_LATENCY_MODE", -1);
+  const bool latency_mode = lat_env >= 0 ? lat_env != 0 : nsolv <= 256;
   // lane-packed 16-bit kernel (pw_wave.h, WaveFill16): LOCAL / B_LOCAL, every running value fits int16.  The
   // score bound is 8000, not 16000: the first diagonal above the band is computed like any other and its offer
   // into the band is lowered by only 8192 (the sentinel), so no score -- in or out of the band -- may reach that
@@ -194,12 +198,10 @@ int batch_build(pw_batch* b) {
     const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
     if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }
     else if (bk1) { pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 0; }
+    // one pair per wavefront with 16+ diagonals per lane is a long serial chain: small batches go multi-wavefront
+    if (latency_mode && pbk >= 16 && !pseg) pbk = 0;
     if (pbk) b->variant = pw::VAR_FAST16;
   }
-  // latency mode: with at most kLatencyPairs pairs the batch is a few wavefronts on a 1024-SIMD chip, so the time is
-  // the length of one pair's dependency chain, not throughput (PWLIB_LATENCY_MODE=0 / 1 overrides)
-  const int lat_env = env_int("PWLIB_LATENCY_MODE", -1);
-  const bool latency_mode = lat_env >= 0 ? lat_env != 0 : nsolv <= 64;
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {
     pw::PairDesc& d = b->descs[k];

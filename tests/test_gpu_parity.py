@@ -513,3 +513,37 @@ def test_adversarial_fuzz_vs_oracle(oracle):
     assert nbad == 0 and npairs > 1000
     nb, npairs, nbad = fz.run(60, 20261005, long_mode=True, max_batches=25)
     assert nbad == 0
+
+
+@pytest.mark.parametrize('latency_mode', ['0', '1'])
+def test_wide_pairs_single_wavefront_and_latency_mode(oracle, latency_mode, monkeypatch):
+    """Bands of 300 .. 2000 diagonals both ways: one wavefront per pair with 8 .. 32 diagonals per lane
+    (PWLIB_LATENCY_MODE=0, the throughput layout) and spread over up to 8 wavefronts with 4 .. 16 per lane
+    (PWLIB_LATENCY_MODE=1, what small batches get by default) -- all types, int32 / f64 / generic."""
+    from biseqt_amd import synth, _pwlib as W
+    from biseqt_amd.batch import BatchAligner
+    monkeypatch.setenv('PWLIB_LATENCY_MODE', latency_mode)
+    rng = synth.rng_for(404)
+    cases = [(700, 1, 1, (-150, 160), 0), (900, 1, 2, (-300, 280), 0), (1000, 1, 0, (-500, 600), W.PW_FLAG_FORCE_F64),
+             (800, 0, 1, None, 0), (1000, 0, 0, None, W.PW_FLAG_FORCE_GENERIC), (600, 0, 4, None, 0), (950, 0, 6, None, 0)]
+    for n, mode, alntype, band, flags in cases:
+        o = synth.rand_seqs(rng, 1, n)[0]
+        m = synth.mutate(rng, o, .08, .03, .4)
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2,
+                  flags=flags)
+        okw = dict(L=4, mode=mode, alntype=alntype, match=1, mismatch=-3, go=-5, ge=-2)
+        if band is not None:
+            kw['diag_range'] = band; okw['diag_range'] = band
+        with BatchAligner([(o, m), (m, o)] if band is None else [(o, m)], **kw) as b:
+            name = b.kernel_name
+            res = b.run()
+            txs = b.transcripts(res)
+        ndiag = (band[1] - band[0] + 1) if band is not None else len(o) + len(m) + 1
+        assert ('k_fill_mw' in name) == (latency_mode == '1' and ndiag > 512), (name, ndiag)
+        r = oracle.solve(o, m, **okw)
+        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'], (n, mode, alntype, name)
+        if r['opt'][0] != -1:
+            assert res['score'][0] == r['score']
+            if not r['would_panick'] and not r['tb_null']:
+                assert txs[0] == r['transcript']
+                assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
