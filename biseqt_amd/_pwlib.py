@@ -128,7 +128,7 @@ SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_se
 
 
 # every symbol include/pw_overlap.h declares
-OVERLAP_EXPORTS = ['pw_overlap_bands', 'pw_overlap_last_ms', 'pw_overlap_last_error']
+OVERLAP_EXPORTS = ['pw_overlap_bands', 'pw_overlap_all_pairs', 'pw_overlap_last_ms', 'pw_overlap_last_error']
 
 
 class pw_read_pair(C.Structure):
@@ -231,6 +231,9 @@ def load():
     # include/pw_overlap.h
     lib.pw_overlap_bands.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib.pw_overlap_all_pairs.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p]
     lib.pw_overlap_last_ms.restype = C.c_double
     lib.pw_overlap_last_error.restype = C.c_char_p
     _lib = lib

@@ -98,9 +98,7 @@ __device__ __forceinline__ double ov_x(int d, int ls, int lt, BandConst c) {
 
 // one workgroup per pair
 __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* hist,
-                                                     const unsigned long long* __restrict__ nrows, const uint32_t* __restrict__ first_e,
-                                                     const uint64_t* __restrict__ ks, const uint32_t* __restrict__ ps,
-                                                     const uint64_t* __restrict__ kt, const uint32_t* __restrict__ pt, int64_t nt,
+                                                     const unsigned long long* __restrict__ nrows, const int32_t* __restrict__ d_first,
                                                      BandConst c, pw_overlap_band* __restrict__ out) {
   __shared__ uint32_t s_sum[256];
   __shared__ double s_w[256];
@@ -183,15 +181,95 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
     o.d_best = dbest; o.n_best = n; o.len_best = L; o.r_best = r;
     o.band_best = (int)(pre(dbest + r + lt) - pre(dbest - r + lt - 1));
     o.tie = s_cnt[0];
-    // first row of the table: the first sorted S element with a match, paired with the first j of its run
-    const uint32_t fe = first_e[p];
-    const int64_t lo = lb_u64(kt, nt, ks[fe]);
-    const int df = (int)ps[fe] - (int)pt[lo];
+    // the diagonal of the first row of the table (k-mer asc, i asc, j asc)
+    const int df = d_first[p];
     (void)eval(df, n, L, r);
     o.d_first = df; o.n_first = n; o.len_first = L; o.r_first = r;
     o.band_first = (int)(pre(df + r + lt) - pre(df - r + lt - 1));
     out[p] = o;
   }
+}
+
+// pair-list path: the first row = the first sorted S element with a match, paired with the first j of its run
+__global__ __launch_bounds__(256) void k_first_d(const uint32_t* __restrict__ first_e, int64_t npairs, const uint64_t* __restrict__ ks,
+                                                 const uint32_t* __restrict__ ps, const uint64_t* __restrict__ kt,
+                                                 const uint32_t* __restrict__ pt, int64_t nt, int32_t* __restrict__ d_first) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= npairs) return;
+  const uint32_t fe = first_e[p];
+  if (fe == 0xffffffffu) { d_first[p] = 0; return; }
+  const int64_t lo = lb_u64(kt, nt, ks[fe]);
+  d_first[p] = (int)ps[fe] - (int)pt[lo];
+}
+
+// ---- all reads against all reads through ONE index (K9) -----------------------------------------------------------
+// K9a: k-mer of every position of every read; value = (read << 32) | pos.  rstart[r] = first k-mer index of read r.
+__global__ __launch_bounds__(256) void k_enc_reads(const uint8_t* __restrict__ arena, const uint64_t* __restrict__ roff,
+                                                   const uint64_t* __restrict__ rstart, int64_t nreads, int64_t total, int k, int L,
+                                                   uint64_t* __restrict__ keys, uint64_t* __restrict__ vals) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int64_t r = ub_u64(rstart, nreads + 1, (uint64_t)g) - 1;
+  const uint32_t q = (uint32_t)(g - (int64_t)rstart[r]);
+  const uint8_t* __restrict__ s = arena + roff[r] + q;
+  uint64_t v = 0;
+  for (int t = 0; t < k; t++) v = v * (uint64_t)L + s[t];
+  keys[g] = v;
+  vals[g] = ((uint64_t)r << 32) | q;
+}
+// K9b: self join.  Inside a run of equal k-mers the entries are ordered by (read, pos); element e pairs with every
+// later entry of a DIFFERENT read: those start at fs[e].
+__global__ __launch_bounds__(256) void k_self_count(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, int64_t n,
+                                                    uint32_t* __restrict__ fs, uint64_t* __restrict__ cnt) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t hi = ub_u64(keys, n, keys[e]);
+  const uint64_t next_read = ((vals[e] >> 32) + 1) << 32;
+  const int64_t f = e + 1 + lb_u64(vals + e + 1, hi - e - 1, next_read);
+  fs[e] = (uint32_t)f;
+  cnt[e] = (uint64_t)(hi - f);
+}
+// one seed per thread: key = rank of the pair (ra < rb) = ra * nreads + rb, value = d = pos_a - pos_b.  Seeds are
+// produced in (k-mer, i, j) order per pair, which a STABLE sort by the pair key keeps.
+__global__ __launch_bounds__(256) void k_self_expand(const uint64_t* __restrict__ off, int64_t n, int64_t nseeds,
+                                                     const uint64_t* __restrict__ vals, const uint32_t* __restrict__ fs,
+                                                     uint64_t nreads, uint64_t* __restrict__ pkey, int32_t* __restrict__ dval) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= nseeds) return;
+  const int64_t e = ub_u64(off, n, (uint64_t)o) - 1;
+  const int64_t f = (int64_t)fs[e] + (o - (int64_t)off[e]);
+  const uint64_t va = vals[e], vb = vals[f];
+  pkey[o] = (va >> 32) * nreads + (vb >> 32);
+  dval[o] = (int32_t)(uint32_t)va - (int32_t)(uint32_t)vb;
+}
+// per candidate pair (unique key u, seeds [soff[u], soff[u] + scount[u])): its reads, histogram base, first diagonal
+__global__ __launch_bounds__(256) void k_cand_pairs(const uint64_t* __restrict__ ukeys, const uint64_t* __restrict__ soff,
+                                                    const int32_t* __restrict__ dval, int64_t np, uint64_t nreads,
+                                                    const uint64_t* __restrict__ roff, const int32_t* __restrict__ rlen,
+                                                    const uint64_t* __restrict__ hbase, DPair* __restrict__ pairs,
+                                                    int32_t* __restrict__ d_first, int32_t* __restrict__ pa, int32_t* __restrict__ pb) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= np) return;
+  const uint64_t a = ukeys[u] / nreads, b = ukeys[u] % nreads;
+  pairs[u] = DPair{roff[a], roff[b], rlen[a], rlen[b], hbase[u]};
+  d_first[u] = dval[soff[u]];
+  pa[u] = (int32_t)a; pb[u] = (int32_t)b;
+}
+__global__ __launch_bounds__(256) void k_pair_hsize(const uint64_t* __restrict__ ukeys, int64_t np, uint64_t nreads,
+                                                    const int32_t* __restrict__ rlen, uint64_t* __restrict__ hsize) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= np) return;
+  hsize[u] = (uint64_t)rlen[ukeys[u] / nreads] + (uint64_t)rlen[ukeys[u] % nreads] + 1;
+}
+// seeds [s0, s1) belong to the pairs [u0, u1) of this chunk; hbase is relative to the chunk's first histogram entry
+__global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict__ dval, int64_t s0, int64_t s1,
+                                                      const uint64_t* __restrict__ soff, int64_t u0, int64_t u1,
+                                                      const DPair* __restrict__ pairs, uint64_t hchunk0, uint32_t* __restrict__ hist) {
+  const int64_t o = s0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= s1) return;
+  const int64_t u = u0 + ub_u64(soff + u0, u1 - u0, (uint64_t)o) - 1;
+  const DPair pr = pairs[u];
+  atomicAdd(&hist[pr.hbase - hchunk0 + (uint64_t)(dval[o] + pr.t_len)], 1u);
 }
 
 struct Buf {
@@ -243,9 +321,13 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
     hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((cs + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t*)ksb.p,
                        (const uint32_t*)psb.p, (int64_t)cs, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
                        (const DPair*)dp.p, kbits, (uint32_t*)hist.p, (unsigned long long*)rows.p, (uint32_t*)first.p);
+  Buf dfirst;
+  if (dfirst.alloc(4 * (size_t)n)) return -1;
+  hipLaunchKernelGGL(k_first_d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const uint32_t*)first.p, n,
+                     (const uint64_t*)ksb.p, (const uint32_t*)psb.p, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
+                     (int32_t*)dfirst.p);
   hipLaunchKernelGGL(k_band_select, dim3((unsigned)n), dim3(256), 0, nullptr, (const DPair*)dp.p, (uint32_t*)hist.p,
-                     (const unsigned long long*)rows.p, (const uint32_t*)first.p, (const uint64_t*)ksb.p, (const uint32_t*)psb.p,
-                     (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct, bc, (pw_overlap_band*)dout.p);
+                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, bc, (pw_overlap_band*)dout.p);
   OV_CHECK(hipEventRecord(ev1, nullptr));
   OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)n, hipMemcpyDeviceToHost));
   OV_CHECK(hipGetLastError());
@@ -255,9 +337,156 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
   return 0;
 }
 
+int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_t* read_len, int64_t R, int L, int k, int kbits,
+                  BandConst bc, int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out, int64_t* n_out, float* ms) {
+  std::vector<uint64_t> rstart((size_t)R + 1);
+  uint64_t K = 0;
+  for (int64_t r = 0; r < R; r++) { rstart[(size_t)r] = K; K += read_len[r] >= k ? (uint64_t)(read_len[r] - k + 1) : 0; }
+  rstart[(size_t)R] = K;
+  *n_out = 0;
+  if (K == 0) return 0;
+  if (K >= (1ull << 32)) { set_err("more than 2^32 k-mers in one index: split the read set"); return -1; }
+  hipEvent_t ev0, ev1;
+  OV_CHECK(hipEventCreate(&ev0)); OV_CHECK(hipEventCreate(&ev1));
+  Buf droff, drlen, drstart, kin, vin, ks, vs, fs, cnt, off, scal, tmp;
+  if (droff.alloc(8 * (size_t)R) || drlen.alloc(4 * (size_t)R) || drstart.alloc(8 * ((size_t)R + 1)) || kin.alloc(8 * (size_t)K) ||
+      vin.alloc(8 * (size_t)K) || ks.alloc(8 * (size_t)K) || vs.alloc(8 * (size_t)K) || fs.alloc(4 * (size_t)K) ||
+      cnt.alloc(8 * (size_t)K) || off.alloc(8 * (size_t)K) || scal.alloc(64)) return -1;
+  OV_CHECK(hipMemcpy(droff.p, read_off, 8 * (size_t)R, hipMemcpyHostToDevice));
+  OV_CHECK(hipMemcpy(drlen.p, read_len, 4 * (size_t)R, hipMemcpyHostToDevice));
+  OV_CHECK(hipMemcpy(drstart.p, rstart.data(), 8 * ((size_t)R + 1), hipMemcpyHostToDevice));
+  OV_CHECK(hipEventRecord(ev0, nullptr));
+  const dim3 blk(256), gK((unsigned)((K + 255) / 256));
+  hipLaunchKernelGGL(k_enc_reads, gK, blk, 0, nullptr, d_arena, (const uint64_t*)droff.p, (const uint64_t*)drstart.p, R, (int64_t)K, k, L,
+                     (uint64_t*)kin.p, (uint64_t*)vin.p);
+  size_t tb = 0;
+  OV_CHECK(rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)kin.p, (uint64_t*)ks.p, (const uint64_t*)vin.p, (uint64_t*)vs.p, (size_t)K,
+                                     0u, (unsigned)kbits, (hipStream_t) nullptr));
+  if (tmp.alloc(tb)) return -1;
+  OV_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, (const uint64_t*)kin.p, (uint64_t*)ks.p, (const uint64_t*)vin.p, (uint64_t*)vs.p, (size_t)K,
+                                     0u, (unsigned)kbits, (hipStream_t) nullptr));
+  hipLaunchKernelGGL(k_self_count, gK, blk, 0, nullptr, (const uint64_t*)ks.p, (const uint64_t*)vs.p, (int64_t)K, (uint32_t*)fs.p, (uint64_t*)cnt.p);
+  size_t tb2 = 0;
+  OV_CHECK(rocprim::exclusive_scan(nullptr, tb2, (const uint64_t*)cnt.p, (uint64_t*)off.p, (uint64_t)0, (size_t)K, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
+  Buf tmp2;
+  if (tmp2.alloc(tb2)) return -1;
+  OV_CHECK(rocprim::exclusive_scan(tmp2.p, tb2, (const uint64_t*)cnt.p, (uint64_t*)off.p, (uint64_t)0, (size_t)K, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
+  uint64_t last_off = 0, last_cnt = 0;
+  OV_CHECK(hipMemcpy(&last_off, (uint64_t*)off.p + (K - 1), 8, hipMemcpyDeviceToHost));
+  OV_CHECK(hipMemcpy(&last_cnt, (uint64_t*)cnt.p + (K - 1), 8, hipMemcpyDeviceToHost));
+  const uint64_t NS = last_off + last_cnt;
+  if (NS == 0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return 0; }
+  if (NS >= (1ull << 32)) { set_err("more than 2^32 seeds between the reads: use a longer word"); return -1; }
+  // seeds -> (pair key, d), stably sorted by the pair key
+  Buf pk_in, dv_in, pk, dv;
+  if (pk_in.alloc(8 * (size_t)NS) || dv_in.alloc(4 * (size_t)NS) || pk.alloc(8 * (size_t)NS) || dv.alloc(4 * (size_t)NS)) return -1;
+  hipLaunchKernelGGL(k_self_expand, dim3((unsigned)((NS + 255) / 256)), blk, 0, nullptr, (const uint64_t*)off.p, (int64_t)K, (int64_t)NS,
+                     (const uint64_t*)vs.p, (const uint32_t*)fs.p, (uint64_t)R, (uint64_t*)pk_in.p, (int32_t*)dv_in.p);
+  int pbits = 1; while ((((uint64_t)R * (uint64_t)R) >> pbits) != 0) pbits++;
+  size_t tb3 = 0;
+  OV_CHECK(rocprim::radix_sort_pairs(nullptr, tb3, (const uint64_t*)pk_in.p, (uint64_t*)pk.p, (const int32_t*)dv_in.p, (int32_t*)dv.p, (size_t)NS,
+                                     0u, (unsigned)pbits, (hipStream_t) nullptr));
+  Buf tmp3;
+  if (tmp3.alloc(tb3)) return -1;
+  OV_CHECK(rocprim::radix_sort_pairs(tmp3.p, tb3, (const uint64_t*)pk_in.p, (uint64_t*)pk.p, (const int32_t*)dv_in.p, (int32_t*)dv.p, (size_t)NS,
+                                     0u, (unsigned)pbits, (hipStream_t) nullptr));
+  // unique pair keys with their seed counts
+  Buf uk, uc, nruns;
+  if (uk.alloc(8 * (size_t)NS) || uc.alloc(8 * (size_t)NS) || nruns.alloc(16)) return -1;
+  size_t tb4 = 0;
+  OV_CHECK(rocprim::run_length_encode(nullptr, tb4, (const uint64_t*)pk.p, (unsigned int)NS, (uint64_t*)uk.p, (unsigned long long*)uc.p,
+                                      (unsigned long long*)nruns.p, (hipStream_t) nullptr));
+  Buf tmp4;
+  if (tmp4.alloc(tb4)) return -1;
+  OV_CHECK(rocprim::run_length_encode(tmp4.p, tb4, (const uint64_t*)pk.p, (unsigned int)NS, (uint64_t*)uk.p, (unsigned long long*)uc.p,
+                                      (unsigned long long*)nruns.p, (hipStream_t) nullptr));
+  unsigned long long NP = 0;
+  OV_CHECK(hipMemcpy(&NP, nruns.p, 8, hipMemcpyDeviceToHost));
+  if ((int64_t)NP > max_pairs) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "%llu pairs of reads share a seed (capacity %lld): raise max_pairs or the word length", NP, (long long)max_pairs);
+    set_err(msg);
+    return -1;
+  }
+  // seed offsets and histogram bases of the candidate pairs
+  Buf soff, hsize, hbase, dpairs, dfirst, dpa, dpb, dout;
+  if (soff.alloc(8 * (size_t)NP) || hsize.alloc(8 * (size_t)NP) || hbase.alloc(8 * (size_t)NP) || dpairs.alloc(sizeof(DPair) * (size_t)NP) ||
+      dfirst.alloc(4 * (size_t)NP) || dpa.alloc(4 * (size_t)NP) || dpb.alloc(4 * (size_t)NP) || dout.alloc(sizeof(pw_overlap_band) * (size_t)NP)) return -1;
+  const dim3 gP((unsigned)((NP + 255) / 256));
+  size_t tb5 = 0;
+  OV_CHECK(rocprim::exclusive_scan(nullptr, tb5, (const uint64_t*)uc.p, (uint64_t*)soff.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
+  Buf tmp5;
+  if (tmp5.alloc(tb5)) return -1;
+  OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)uc.p, (uint64_t*)soff.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
+  hipLaunchKernelGGL(k_pair_hsize, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (int64_t)NP, (uint64_t)R, (const int32_t*)drlen.p, (uint64_t*)hsize.p);
+  OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)hsize.p, (uint64_t*)hbase.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
+  hipLaunchKernelGGL(k_cand_pairs, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (const uint64_t*)soff.p, (const int32_t*)dv.p, (int64_t)NP, (uint64_t)R,
+                     (const uint64_t*)droff.p, (const int32_t*)drlen.p, (const uint64_t*)hbase.p, (DPair*)dpairs.p, (int32_t*)dfirst.p,
+                     (int32_t*)dpa.p, (int32_t*)dpb.p);
+  // chunks of pairs whose histograms fit 2^30 counters
+  std::vector<uint64_t> h_hbase((size_t)NP), h_soff((size_t)NP), h_hsize((size_t)NP);
+  OV_CHECK(hipMemcpy(h_hbase.data(), hbase.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
+  OV_CHECK(hipMemcpy(h_soff.data(), soff.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
+  OV_CHECK(hipMemcpy(h_hsize.data(), hsize.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
+  const uint64_t cap = 1ull << 30;
+  Buf hist;
+  uint64_t hist_cap = 0;
+  for (uint64_t u0 = 0; u0 < NP;) {
+    uint64_t u1 = u0, tot = 0;
+    while (u1 < NP && (u1 == u0 || tot + h_hsize[(size_t)u1] <= cap)) { tot += h_hsize[(size_t)u1]; u1++; }
+    if (tot > hist_cap) { if (hist.p) { (void)hipFree(hist.p); hist.p = nullptr; } if (hist.alloc(4 * (size_t)tot)) return -1; hist_cap = tot; }
+    OV_CHECK(hipMemsetAsync(hist.p, 0, 4 * (size_t)tot, nullptr));
+    const uint64_t s0 = h_soff[(size_t)u0], s1 = u1 < NP ? h_soff[(size_t)u1] : NS;
+    hipLaunchKernelGGL(k_scatter_hist, dim3((unsigned)((s1 - s0 + 255) / 256)), blk, 0, nullptr, (const int32_t*)dv.p, (int64_t)s0, (int64_t)s1,
+                       (const uint64_t*)soff.p, (int64_t)u0, (int64_t)u1, (const DPair*)dpairs.p, h_hbase[(size_t)u0], (uint32_t*)hist.p);
+    // band_select indexes its histogram as hist + pair.hbase: shift the base pointer by the chunk's first entry
+    hipLaunchKernelGGL(k_band_select, dim3((unsigned)(u1 - u0)), blk, 0, nullptr, (const DPair*)dpairs.p + u0,
+                       (uint32_t*)hist.p - h_hbase[(size_t)u0], (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, bc,
+                       (pw_overlap_band*)dout.p + u0);
+    u0 = u1;
+  }
+  OV_CHECK(hipEventRecord(ev1, nullptr));
+  OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)NP, hipMemcpyDeviceToHost));
+  OV_CHECK(hipMemcpy(pair_a, dpa.p, 4 * (size_t)NP, hipMemcpyDeviceToHost));
+  OV_CHECK(hipMemcpy(pair_b, dpb.p, 4 * (size_t)NP, hipMemcpyDeviceToHost));
+  OV_CHECK(hipGetLastError());
+  float t = 0.f;
+  OV_CHECK(hipEventElapsedTime(&t, ev0, ev1));
+  *ms = t;
+  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+  *n_out = (int64_t)NP;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int pw_overlap_all_pairs(int device, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* read_off, const int32_t* read_len,
+                         int64_t n_reads, int alphabet_len, int wordlen, double len_coeff, double radius_coeff, double word_p_null,
+                         int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out, int64_t* n_out) {
+  if (alphabet_len < 1 || alphabet_len > 36 || wordlen < 1 || wordlen > 31) { set_err("alphabet_len 1..36, wordlen 1..31"); return -1; }
+  if (n_reads < 0 || n_reads >= (1ll << 31) || !n_out || (n_reads && (!read_off || !read_len))) { set_err("bad arguments"); return -1; }
+  if (!(len_coeff > 0) || !(radius_coeff > 0) || !(word_p_null > 0)) { set_err("coefficients must be positive"); return -1; }
+  uint64_t kmax = 1; int kbits = 0;
+  for (int i = 0; i < wordlen; i++) { if (kmax > (1ull << 62) / (uint64_t)alphabet_len) { set_err("alphabet_len ^ wordlen must be below 2^62"); return -1; } kmax *= (uint64_t)alphabet_len; }
+  while (((kmax - 1) >> kbits) != 0) kbits++;
+  if (kbits == 0) kbits = 1;
+  for (int64_t r = 0; r < n_reads; r++)
+    if (read_len[r] < 0 || read_off[r] + (uint64_t)read_len[r] > arena_bytes) { set_err("a read lies outside the arena"); return -1; }
+  for (uint64_t i = 0; i < arena_bytes; i++) if (arena[i] >= alphabet_len) { set_err("letter outside the alphabet"); return -1; }
+  g_ms = 0.0; *n_out = 0;
+  if (n_reads < 2) return 0;
+  OV_CHECK(hipSetDevice(device));
+  Buf d_arena;
+  if (d_arena.alloc((size_t)arena_bytes + 64)) return -1;
+  OV_CHECK(hipMemcpy(d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice));
+  float ms = 0.f;
+  const int rc = run_all_pairs((const uint8_t*)d_arena.p, read_off, read_len, n_reads, alphabet_len, wordlen, kbits,
+                               BandConst{len_coeff, radius_coeff, word_p_null}, max_pairs, pair_a, pair_b, out, n_out, &ms);
+  g_ms = (double)ms;
+  return rc;
+}
 
 const char* pw_overlap_last_error(void) { return g_err.c_str(); }
 double pw_overlap_last_ms(void) { return g_ms; }

@@ -78,11 +78,9 @@ def _result(d, rad, L, n_in_band, word_p, alphabet_len, wordlen):
     return res
 
 
-def overlap_bands(reads, pairs, wordlen, alphabet, g_max, sensitivity, device=0, stats=None):
-    """``highest_scoring_overlap_band()`` of every pair ``(i, j)`` (``reads[i]`` as S, ``reads[j]`` as T)."""
-    assert isinstance(alphabet, Alphabet)
+def _records_to_results(reads, pairs, recs, wordlen, alphabet, g_max, sensitivity, device):
+    """Device records -> the reference's dicts (shared by the pair-list and the all-pairs paths)."""
     L = len(alphabet)
-    recs, ms = raw_bands(reads, pairs, wordlen, L, g_max, sensitivity, device)
     out, n_fallback = [], 0
     for q, r in enumerate(recs):
         if r['n_seeds'] == 0:
@@ -101,9 +99,54 @@ def overlap_bands(reads, pairs, wordlen, alphabet, g_max, sensitivity, device=0,
             n_fallback += 1
         else:
             out.append(_result(int(r['d_best']), int(r['r_best']), int(r['len_best']), int(r['band_best']), float(r['w_best']), L, wordlen))
+    return out, n_fallback
+
+
+def overlap_bands(reads, pairs, wordlen, alphabet, g_max, sensitivity, device=0, stats=None):
+    """``highest_scoring_overlap_band()`` of every pair ``(i, j)`` (``reads[i]`` as S, ``reads[j]`` as T)."""
+    assert isinstance(alphabet, Alphabet)
+    recs, ms = raw_bands(reads, pairs, wordlen, len(alphabet), g_max, sensitivity, device)
+    out, n_fallback = _records_to_results(reads, pairs, recs, wordlen, alphabet, g_max, sensitivity, device)
     if stats is not None:
         stats.update(device_ms=ms, fallback_pairs=n_fallback, pairs=len(pairs))
     return out
+
+
+def raw_all_pairs(reads, wordlen, alphabet_len, g_max, sensitivity, device=0, max_pairs=None):
+    """All pairs ``a < b`` of ``reads`` that share at least one seed, through ONE k-mer index over all reads:
+    returns ``(pairs (n, 2) int32, records BAND_DTYPE, device ms)``."""
+    assert 0 < g_max < 1 and 0 < sensitivity < 1
+    lib = W.load()
+    arena, offs, arrs = _arena(reads)
+    R = len(arrs)
+    cap = int(max_pairs) if max_pairs is not None else min(R * (R - 1) // 2, 1 << 26)
+    pa, pb = np.zeros(max(cap, 1), np.int32), np.zeros(max(cap, 1), np.int32)
+    out = np.zeros(max(cap, 1), BAND_DTYPE)
+    n_out = C.c_int64(0)
+    roff = np.ascontiguousarray(offs[:-1].astype(np.uint64))
+    rlen = np.ascontiguousarray(np.diff(offs).astype(np.int32))
+    arena_c = np.ascontiguousarray(arena)
+    rc = lib.pw_overlap_all_pairs(device, arena_c.ctypes.data, arena_c.size, roff.ctypes.data, rlen.ctypes.data, R, alphabet_len,
+                                  wordlen, float(2. / (2 - g_max)), float(erfcinv(1. - sensitivity) * np.sqrt(2 * g_max)),
+                                  float((1. / alphabet_len) ** wordlen), cap, pa.ctypes.data, pb.ctypes.data, out.ctypes.data,
+                                  C.byref(n_out))
+    if rc != 0:
+        raise RuntimeError('pw_overlap_all_pairs failed: ' + (lib.pw_overlap_last_error() or b'').decode())
+    n = n_out.value
+    return np.stack([pa[:n], pb[:n]], axis=1), out[:n], lib.pw_overlap_last_ms()
+
+
+def overlap_all_pairs(reads, wordlen, alphabet, g_max, sensitivity, device=0, max_pairs=None, stats=None):
+    """The reference's all-pairs loop (``experiments/blot_overlaps.py:262-272``) in one device pass: returns a dict
+    ``{(a, b): highest_scoring_overlap_band()}`` for the pairs ``a < b`` that share a seed; for every other pair the
+    reference's answer is None."""
+    assert isinstance(alphabet, Alphabet)
+    pairs, recs, ms = raw_all_pairs(reads, wordlen, len(alphabet), g_max, sensitivity, device, max_pairs)
+    plist = [(int(a), int(b)) for a, b in pairs.tolist()]
+    res, n_fallback = _records_to_results(reads, plist, recs, wordlen, alphabet, g_max, sensitivity, device)
+    if stats is not None:
+        stats.update(device_ms=ms, fallback_pairs=n_fallback, pairs=len(plist))
+    return dict(zip(plist, res))
 
 
 def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, **aligner_kw):

@@ -79,3 +79,36 @@ def test_config4_flow_bands_then_banded_overlap_alignment(oracle):
         elif true_overlap(i, j) < -200:
             assert band is None or band['p'] < .8
     assert found >= 5
+
+
+@pytest.mark.parametrize('wordlen', [8, 11])
+def test_all_pairs_one_index_vs_pair_list_and_oracle(wordlen):
+    """pw_overlap_all_pairs (one k-mer index over all reads, self join) must list exactly the pairs that share a seed
+    and give each the record of the pair-list path; a sample is compared with the oracle directly."""
+    from biseqt_amd import synth
+    from biseqt_amd.overlap import overlap_all_pairs, raw_all_pairs, raw_bands
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO, seeds_oracle as SO
+    A = Alphabet('ACGT')
+    rng = synth.rng_for(77 + wordlen)
+    reads, starts = _reads(rng, 9000, 30, 1200, .04, .03)
+    reads.append(synth.rand_seqs(rng, 1, 300)[0])
+    reads.append(np.zeros(5, np.uint8))                     # shorter than the word for wordlen 8 / 11
+    reads.append(reads[3].copy())
+    pairs, recs, ms = raw_all_pairs(reads, wordlen, 4, .2, .99)
+    all_pairs = list(itertools.combinations(range(len(reads)), 2))
+    ref_recs, _ = raw_bands(reads, all_pairs, wordlen, 4, .2, .99)
+    with_seeds = [p for p, r in zip(all_pairs, ref_recs) if r['n_seeds'] > 0]
+    assert [tuple(p) for p in pairs.tolist()] == with_seeds
+    want = np.array([r for r in ref_recs if r['n_seeds'] > 0], dtype=ref_recs.dtype)
+    for name in recs.dtype.names:
+        if name != 'pad_':
+            assert (recs[name] == want[name]).all(), name
+    res = overlap_all_pairs(reads, wordlen, A, .2, .99)
+    assert list(res.keys()) == with_seeds
+    for (a, b) in with_seeds[::7]:
+        if len(reads[a]) == len(reads[b]) and (reads[a] == reads[b]).all():
+            continue
+        e = BO.highest_scoring_overlap_band(reads[a].tolist(), reads[b].tolist(), wordlen, 4, .2, .99)
+        g = res[(a, b)]
+        assert g['d_band'] == e['d_band'] and g['p'] == e['p'] and g['len'] == e['len'] and g['score'] == e['score']
