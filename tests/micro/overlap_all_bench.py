@@ -1,0 +1,66 @@
+"""Config 4 through ONE index over all reads: R synthetic 5 kb reads at 25x coverage, every pair of reads.
+
+    python tests/micro/overlap_all_bench.py [n_reads] [wordlen]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from biseqt_amd import synth                            # noqa: E402
+from biseqt_amd.overlap import raw_all_pairs            # noqa: E402
+from biseqt_amd.batch import BatchAligner             # noqa: E402
+from biseqt_amd import _pwlib as W                     # noqa: E402
+
+
+def main():
+    R = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+    k = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    rng = synth.rng_for(4)
+    read_len, cov = 5000, 25
+    G = R * read_len // cov
+    g = synth.rand_seqs(rng, 1, G)[0]
+    starts = rng.integers(0, G - read_len, R)
+    t0 = time.perf_counter()
+    reads = [synth.mutate(rng, g[s:s + read_len], .05, .025, .025) for s in starts]
+    t1 = time.perf_counter()
+    raw_all_pairs(reads[:50], k, 4, .2, .9)
+    t2 = time.perf_counter()
+    pairs, recs, ms = raw_all_pairs(reads, k, 4, .2, .9, max_pairs=min(R * (R - 1) // 2, 1 << 23))
+    t3 = time.perf_counter()
+    w = recs['w_best']
+    p = np.where(w > 0, np.exp(np.log(np.maximum(w, 1e-300)) / k), 0.0)
+    pos = p >= .8
+    ov = np.minimum(starts[pairs[:, 0]], starts[pairs[:, 1]]) + read_len - np.maximum(starts[pairs[:, 0]], starts[pairs[:, 1]])
+    # true overlaps among ALL pairs (sorted starts sweep)
+    order = np.argsort(starts); ss = starts[order]
+    true_total = int(sum(np.searchsorted(ss, ss[i] + read_len - 500, 'left') - i - 1 for i in range(R)))
+    print('%d reads (%.1f Mb of reads, genome %d), %d pairs, k=%d: one index, device %.1f ms (wall %.2f s; reads generated in %.1f s)'
+          % (R, R * read_len / 1e6, G, R * (R - 1) // 2, k, ms, t3 - t2, t1 - t0))
+    print('  candidate pairs sharing a seed: %d (%d seeds); p >= 0.8: %d pairs, of which overlapping > 500 bases: %d, not overlapping: %d; '
+          'true overlaps > 500 bases in the read set: %d' % (len(pairs), int(recs['n_seeds'].sum()), int(pos.sum()),
+                                                            int((pos & (ov > 500)).sum()), int((pos & (ov <= 0)).sum()), true_total))
+    print('  %.2f G pairs/s of the all-pairs space, %.2f M candidate pairs/s' % (R * (R - 1) / 2 / ms / 1e6, len(pairs) / ms / 1e3))
+    # banded overlap alignment (B_OVERLAP, 1/-3/-5/-2) of the first NA positive pairs in one batch
+    NA = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+    sel = np.flatnonzero(pos)[:NA]
+    bp = [(reads[pairs[q, 0]], reads[pairs[q, 1]]) for q in sel]
+    dr = [(max(int(recs['d_best'][q] - recs['r_best'][q]), -len(reads[pairs[q, 1]])),
+           min(int(recs['d_best'][q] + recs['r_best'][q]), len(reads[pairs[q, 0]]))) for q in sel]
+    t4 = time.perf_counter()
+    with BatchAligner(bp, alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP, alphabet_len=4, diag_range=dr, match_score=1,
+                      mismatch_score=-3, go_score=-5, ge_score=-2, flags=W.PW_FLAG_PROFILE) as b:
+        t5 = time.perf_counter()
+        b.solve(); b.traceback(); b.sync()
+        b.solve(); b.traceback(); b.sync()
+        res = b.results()
+        print('  banded overlap alignment of %d pairs: planning + upload %.2f s; fill %.1f ms + traceback %.1f ms for %.3g cells = %.0f GCUPS (%s); '
+              'mean score %.0f' % (len(sel), t5 - t4, b.fill_ms(), b.trace_ms(), b.cells, b.cells / (b.fill_ms() + b.trace_ms()) / 1e6,
+                                   b.kernel_name, float(res['score'].mean())))
+
+
+if __name__ == '__main__':
+    main()
