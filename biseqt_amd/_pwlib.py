@@ -232,8 +232,8 @@ def load():
     lib.pw_overlap_bands.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                      C.c_double, C.c_double, C.c_double, C.c_void_p]
     lib.pw_overlap_all_pairs.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
-                                         C.c_double, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p]
+                                         C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
     lib.pw_overlap_last_ms.restype = C.c_double
     lib.pw_overlap_last_error.restype = C.c_char_p
     _lib = lib

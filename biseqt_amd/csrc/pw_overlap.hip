@@ -220,9 +220,11 @@ __global__ __launch_bounds__(256) void k_enc_reads(const uint8_t* __restrict__ a
 // K9b: self join.  Inside a run of equal k-mers the entries are ordered by (read, pos); element e pairs with every
 // later entry of a DIFFERENT read: those start at fs[e].
 __global__ __launch_bounds__(256) void k_self_count(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ vals, int64_t n,
-                                                    uint32_t* __restrict__ fs, uint64_t* __restrict__ cnt) {
+                                                    int shard_rank, int shard_world, uint32_t* __restrict__ fs, uint64_t* __restrict__ cnt) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
+  // multi-GPU: the pairs (a, b), a < b, are dealt round-robin by a; every rank joins only its own share
+  if ((int)((vals[e] >> 32) % (uint64_t)shard_world) != shard_rank) { fs[e] = (uint32_t)e; cnt[e] = 0; return; }
   const int64_t hi = ub_u64(keys, n, keys[e]);
   const uint64_t next_read = ((vals[e] >> 32) + 1) << 32;
   const int64_t f = e + 1 + lb_u64(vals + e + 1, hi - e - 1, next_read);
@@ -338,7 +340,8 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
 }
 
 int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_t* read_len, int64_t R, int L, int k, int kbits,
-                  BandConst bc, int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out, int64_t* n_out, float* ms) {
+                  BandConst bc, int shard_rank, int shard_world, int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out,
+                  int64_t* n_out, float* ms) {
   std::vector<uint64_t> rstart((size_t)R + 1);
   uint64_t K = 0;
   for (int64_t r = 0; r < R; r++) { rstart[(size_t)r] = K; K += read_len[r] >= k ? (uint64_t)(read_len[r] - k + 1) : 0; }
@@ -365,7 +368,8 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   if (tmp.alloc(tb)) return -1;
   OV_CHECK(rocprim::radix_sort_pairs(tmp.p, tb, (const uint64_t*)kin.p, (uint64_t*)ks.p, (const uint64_t*)vin.p, (uint64_t*)vs.p, (size_t)K,
                                      0u, (unsigned)kbits, (hipStream_t) nullptr));
-  hipLaunchKernelGGL(k_self_count, gK, blk, 0, nullptr, (const uint64_t*)ks.p, (const uint64_t*)vs.p, (int64_t)K, (uint32_t*)fs.p, (uint64_t*)cnt.p);
+  hipLaunchKernelGGL(k_self_count, gK, blk, 0, nullptr, (const uint64_t*)ks.p, (const uint64_t*)vs.p, (int64_t)K, shard_rank, shard_world,
+                     (uint32_t*)fs.p, (uint64_t*)cnt.p);
   size_t tb2 = 0;
   OV_CHECK(rocprim::exclusive_scan(nullptr, tb2, (const uint64_t*)cnt.p, (uint64_t*)off.p, (uint64_t)0, (size_t)K, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
   Buf tmp2;
@@ -464,10 +468,12 @@ extern "C" {
 
 int pw_overlap_all_pairs(int device, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* read_off, const int32_t* read_len,
                          int64_t n_reads, int alphabet_len, int wordlen, double len_coeff, double radius_coeff, double word_p_null,
-                         int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out, int64_t* n_out) {
+                         int shard_rank, int shard_world, int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out,
+                         int64_t* n_out) {
   if (alphabet_len < 1 || alphabet_len > 36 || wordlen < 1 || wordlen > 31) { set_err("alphabet_len 1..36, wordlen 1..31"); return -1; }
   if (n_reads < 0 || n_reads >= (1ll << 31) || !n_out || (n_reads && (!read_off || !read_len))) { set_err("bad arguments"); return -1; }
   if (!(len_coeff > 0) || !(radius_coeff > 0) || !(word_p_null > 0)) { set_err("coefficients must be positive"); return -1; }
+  if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) { set_err("bad shard"); return -1; }
   uint64_t kmax = 1; int kbits = 0;
   for (int i = 0; i < wordlen; i++) { if (kmax > (1ull << 62) / (uint64_t)alphabet_len) { set_err("alphabet_len ^ wordlen must be below 2^62"); return -1; } kmax *= (uint64_t)alphabet_len; }
   while (((kmax - 1) >> kbits) != 0) kbits++;
@@ -483,7 +489,8 @@ int pw_overlap_all_pairs(int device, const uint8_t* arena, uint64_t arena_bytes,
   OV_CHECK(hipMemcpy(d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice));
   float ms = 0.f;
   const int rc = run_all_pairs((const uint8_t*)d_arena.p, read_off, read_len, n_reads, alphabet_len, wordlen, kbits,
-                               BandConst{len_coeff, radius_coeff, word_p_null}, max_pairs, pair_a, pair_b, out, n_out, &ms);
+                               BandConst{len_coeff, radius_coeff, word_p_null}, shard_rank, shard_world, max_pairs, pair_a, pair_b, out,
+                               n_out, &ms);
   g_ms = (double)ms;
   return rc;
 }

@@ -112,9 +112,10 @@ def overlap_bands(reads, pairs, wordlen, alphabet, g_max, sensitivity, device=0,
     return out
 
 
-def raw_all_pairs(reads, wordlen, alphabet_len, g_max, sensitivity, device=0, max_pairs=None):
+def raw_all_pairs(reads, wordlen, alphabet_len, g_max, sensitivity, device=0, max_pairs=None, rank=0, world=1):
     """All pairs ``a < b`` of ``reads`` that share at least one seed, through ONE k-mer index over all reads:
-    returns ``(pairs (n, 2) int32, records BAND_DTYPE, device ms)``."""
+    returns ``(pairs (n, 2) int32, records BAND_DTYPE, device ms)``.  With ``world > 1`` only the pairs whose smaller
+    read index is ``rank`` modulo ``world`` (one process per GPU, no data-path collective)."""
     assert 0 < g_max < 1 and 0 < sensitivity < 1
     lib = W.load()
     arena, offs, arrs = _arena(reads)
@@ -128,7 +129,7 @@ def raw_all_pairs(reads, wordlen, alphabet_len, g_max, sensitivity, device=0, ma
     arena_c = np.ascontiguousarray(arena)
     rc = lib.pw_overlap_all_pairs(device, arena_c.ctypes.data, arena_c.size, roff.ctypes.data, rlen.ctypes.data, R, alphabet_len,
                                   wordlen, float(2. / (2 - g_max)), float(erfcinv(1. - sensitivity) * np.sqrt(2 * g_max)),
-                                  float((1. / alphabet_len) ** wordlen), cap, pa.ctypes.data, pb.ctypes.data, out.ctypes.data,
+                                  float((1. / alphabet_len) ** wordlen), int(rank), int(world), cap, pa.ctypes.data, pb.ctypes.data, out.ctypes.data,
                                   C.byref(n_out))
     if rc != 0:
         raise RuntimeError('pw_overlap_all_pairs failed: ' + (lib.pw_overlap_last_error() or b'').decode())
@@ -189,3 +190,26 @@ def raw_bands_sharded(reads, pairs, wordlen, alphabet_len, g_max, sensitivity, r
     recs, _ = raw_bands(reads, [pairs[q] for q in mine], wordlen, alphabet_len, g_max, sensitivity,
                         device=rank if device is None else device)
     return gather_struct(recs, len(pairs), rank, world, device=gather_device)
+
+
+def raw_all_pairs_sharded(reads, wordlen, alphabet_len, g_max, sensitivity, rank, world, device=None, max_pairs=None):
+    """Config 4 across GPUs: every rank indexes all reads (cheap) and joins / scores the pairs whose smaller read
+    index is ``rank`` modulo ``world``; pair lists and 64-byte records are gathered to rank 0 (ragged byte gather over
+    ``torch.distributed``) and merged in ascending (a, b) order.  Returns ``(pairs, records)`` on rank 0, None elsewhere."""
+    import torch
+    from .distributed import gather_bytes
+    pairs, recs, _ = raw_all_pairs(reads, wordlen, alphabet_len, g_max, sensitivity, device=rank if device is None else device,
+                                   max_pairs=max_pairs, rank=rank, world=world)
+    blob = np.concatenate([np.ascontiguousarray(pairs, np.int32).view(np.uint8).reshape(-1), recs.view(np.uint8).reshape(-1)])
+    got = gather_bytes(torch.from_numpy(blob.copy()), rank, world)
+    if rank != 0:
+        return None
+    all_pairs, all_recs = [], []
+    for t in got:
+        raw = t.cpu().numpy()
+        n = raw.size // (8 + BAND_DTYPE.itemsize)
+        all_pairs.append(raw[:8 * n].view(np.int32).reshape(n, 2))
+        all_recs.append(raw[8 * n:].view(BAND_DTYPE))
+    pairs, recs = np.concatenate(all_pairs), np.concatenate(all_recs)
+    order = np.lexsort((pairs[:, 1], pairs[:, 0]))
+    return pairs[order], recs[order]

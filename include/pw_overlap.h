@@ -57,11 +57,14 @@ int pw_overlap_bands(int device, const uint8_t* arena, uint64_t arena_bytes, con
  * that share at least one seed are found by a self join of the index; every other pair has no seeds and the
  * reference returns None for it.  read a plays S and read b plays T, as in the reference's double loop
  * (experiments/blot_overlaps.py:267-271).  On return *n_out pairs are listed in pair_a / pair_b (ascending
- * (a, b)) with their records in out; capacity max_pairs each.  Returns 0 or -1. */
+ * (a, b)) with their records in out; capacity max_pairs each.  Multi-GPU: rank shard_rank of shard_world scores
+ * only the pairs with a mod shard_world == shard_rank (no data-path collective; (0, 1) = everything).
+ * Returns 0 or -1. */
 int pw_overlap_all_pairs(int device, const uint8_t* arena, uint64_t arena_bytes, const uint64_t* read_off,
                          const int32_t* read_len, int64_t n_reads, int alphabet_len, int wordlen, double len_coeff,
-                         double radius_coeff, double word_p_null, int64_t max_pairs, int32_t* pair_a,
-                         int32_t* pair_b, pw_overlap_band* out, int64_t* n_out);
+                         double radius_coeff, double word_p_null, int shard_rank, int shard_world,
+                         int64_t max_pairs, int32_t* pair_a, int32_t* pair_b, pw_overlap_band* out,
+                         int64_t* n_out);
 
 double pw_overlap_last_ms(void);           /* device time of the last call (HIP events) */
 const char* pw_overlap_last_error(void);

@@ -112,3 +112,24 @@ def test_all_pairs_one_index_vs_pair_list_and_oracle(wordlen):
         e = BO.highest_scoring_overlap_band(reads[a].tolist(), reads[b].tolist(), wordlen, 4, .2, .99)
         g = res[(a, b)]
         assert g['d_band'] == e['d_band'] and g['p'] == e['p'] and g['len'] == e['len'] and g['score'] == e['score']
+
+
+def test_all_pairs_shards_partition_the_work():
+    """world = 3 simulated on one GPU: the three shards are disjoint, cover exactly the unsharded pair list and carry
+    the same records (what raw_all_pairs_sharded gathers)."""
+    from biseqt_amd import synth
+    from biseqt_amd.overlap import raw_all_pairs
+    rng = synth.rng_for(123)
+    reads, _ = _reads(rng, 8000, 40, 1000, .03, .02)
+    pairs, recs, _ = raw_all_pairs(reads, 10, 4, .2, .99)
+    got_p, got_r = [], []
+    for rank in range(3):
+        p, r, _ = raw_all_pairs(reads, 10, 4, .2, .99, rank=rank, world=3)
+        assert (p[:, 0] % 3 == rank).all()
+        got_p.append(p); got_r.append(r)
+    gp, gr = np.concatenate(got_p), np.concatenate(got_r)
+    order = np.lexsort((gp[:, 1], gp[:, 0]))
+    assert (gp[order] == pairs).all()
+    for name in recs.dtype.names:
+        if name != 'pad_':
+            assert (gr[order][name] == recs[name]).all(), name
