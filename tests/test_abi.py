@@ -125,3 +125,27 @@ def test_product_does_not_import_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt, f
                 assert 'pw_oracle' not in txt and 'emu_wave' not in txt, f
+
+
+def test_seed_and_overlap_entry_points_reject_bad_input_loudly():
+    """Argument validation happens before any device work: NULL / -1 plus a message, never a silent fallback."""
+    import numpy as np
+    lib = W.load()
+    s = np.array([0, 1, 2, 3, 0, 1], np.uint8)
+    bad = np.array([0, 1, 9, 3], np.uint8)
+    none = C.POINTER(C.c_uint64)()
+    assert not lib.pw_seeds_create(0, s.ctypes.data, len(s), s.ctypes.data, len(s), 0, 3, none, 0, -1)
+    assert b'alphabet_len' in lib.pw_seeds_last_error()
+    assert not lib.pw_seeds_create(0, s.ctypes.data, len(s), s.ctypes.data, len(s), 4, 40, none, 0, -1)
+    assert b'wordlen' in lib.pw_seeds_last_error()
+    assert not lib.pw_seeds_create(0, s.ctypes.data, len(s), s.ctypes.data, len(s), 4, 31, none, 0, -1)
+    assert b'2^62' in lib.pw_seeds_last_error()
+    assert not lib.pw_seeds_create(0, bad.ctypes.data, len(bad), s.ctypes.data, len(s), 4, 3, none, 0, 0)
+    assert b'letter outside the alphabet' in lib.pw_seeds_last_error()
+    assert lib.pw_seeds_build(None, 0, None) == -1
+    rp = (W.pw_read_pair * 1)(W.pw_read_pair(0, 4, 4, 10))          # the second read runs past the arena
+    out = np.zeros(64, np.uint8)
+    assert lib.pw_overlap_bands(0, s.ctypes.data, len(s), rp, 1, 4, 3, 1.1, 0.7, 1. / 64, out.ctypes.data) == -1
+    assert b'outside the arena' in lib.pw_overlap_last_error()
+    assert lib.pw_overlap_bands(0, s.ctypes.data, len(s), rp, 1, 4, 3, 0.0, 0.7, 1. / 64, out.ctypes.data) == -1
+    assert b'coefficients' in lib.pw_overlap_last_error()
