@@ -99,14 +99,14 @@ __device__ __forceinline__ double ov_x(int d, int ls, int lt, BandConst c) {
 // one workgroup per pair
 __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* hist,
                                                      const unsigned long long* __restrict__ nrows, const int32_t* __restrict__ d_first,
-                                                     BandConst c, pw_overlap_band* __restrict__ out) {
+                                                     uint64_t hist_first, BandConst c, pw_overlap_band* __restrict__ out) {
   __shared__ uint32_t s_sum[256];
   __shared__ double s_w[256];
   __shared__ int s_d[256], s_cnt[256];
   const int p = (int)blockIdx.x, tid = (int)threadIdx.x;
   const DPair pr = pairs[p];
   const int ls = pr.s_len, lt = pr.t_len, nd = ls + lt + 1;
-  uint32_t* h = hist + pr.hbase;                       // index dd = d + lt (written and re-read across the workgroup)
+  uint32_t* h = hist + (pr.hbase - hist_first);        // `hist` starts at counter hist_first; index dd = d + lt
   pw_overlap_band o;
   memset(&o, 0, sizeof o);
   o.n_seeds = (int64_t)nrows[p];
@@ -274,6 +274,12 @@ __global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict_
   atomicAdd(&hist[pr.hbase - hchunk0 + (uint64_t)(dval[o] + pr.t_len)], 1u);
 }
 
+struct Ev {
+  hipEvent_t e = nullptr;
+  int make() { OV_CHECK(hipEventCreate(&e)); return 0; }
+  ~Ev() { if (e) (void)hipEventDestroy(e); }
+};
+
 struct Buf {
   void* p = nullptr;
   int alloc(size_t bytes) { OV_CHECK(hipMalloc(&p, bytes ? bytes : 16)); return 0; }
@@ -329,7 +335,7 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
                      (const uint64_t*)ksb.p, (const uint32_t*)psb.p, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
                      (int32_t*)dfirst.p);
   hipLaunchKernelGGL(k_band_select, dim3((unsigned)n), dim3(256), 0, nullptr, (const DPair*)dp.p, (uint32_t*)hist.p,
-                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, bc, (pw_overlap_band*)dout.p);
+                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, (uint64_t)0, bc, (pw_overlap_band*)dout.p);
   OV_CHECK(hipEventRecord(ev1, nullptr));
   OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)n, hipMemcpyDeviceToHost));
   OV_CHECK(hipGetLastError());
@@ -349,8 +355,9 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   *n_out = 0;
   if (K == 0) return 0;
   if (K >= (1ull << 32)) { set_err("more than 2^32 k-mers in one index: split the read set"); return -1; }
-  hipEvent_t ev0, ev1;
-  OV_CHECK(hipEventCreate(&ev0)); OV_CHECK(hipEventCreate(&ev1));
+  Ev e0, e1;
+  if (e0.make() || e1.make()) return -1;
+  const hipEvent_t ev0 = e0.e, ev1 = e1.e;
   Buf droff, drlen, drstart, kin, vin, ks, vs, fs, cnt, off, scal, tmp;
   if (droff.alloc(8 * (size_t)R) || drlen.alloc(4 * (size_t)R) || drstart.alloc(8 * ((size_t)R + 1)) || kin.alloc(8 * (size_t)K) ||
       vin.alloc(8 * (size_t)K) || ks.alloc(8 * (size_t)K) || vs.alloc(8 * (size_t)K) || fs.alloc(4 * (size_t)K) ||
@@ -379,7 +386,7 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   OV_CHECK(hipMemcpy(&last_off, (uint64_t*)off.p + (K - 1), 8, hipMemcpyDeviceToHost));
   OV_CHECK(hipMemcpy(&last_cnt, (uint64_t*)cnt.p + (K - 1), 8, hipMemcpyDeviceToHost));
   const uint64_t NS = last_off + last_cnt;
-  if (NS == 0) { (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); return 0; }
+  if (NS == 0) return 0;
   if (NS >= (1ull << 32)) { set_err("more than 2^32 seeds between the reads: use a longer word"); return -1; }
   // seeds -> (pair key, d), stably sorted by the pair key
   Buf pk_in, dv_in, pk, dv;
@@ -443,9 +450,8 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
     const uint64_t s0 = h_soff[(size_t)u0], s1 = u1 < NP ? h_soff[(size_t)u1] : NS;
     hipLaunchKernelGGL(k_scatter_hist, dim3((unsigned)((s1 - s0 + 255) / 256)), blk, 0, nullptr, (const int32_t*)dv.p, (int64_t)s0, (int64_t)s1,
                        (const uint64_t*)soff.p, (int64_t)u0, (int64_t)u1, (const DPair*)dpairs.p, h_hbase[(size_t)u0], (uint32_t*)hist.p);
-    // band_select indexes its histogram as hist + pair.hbase: shift the base pointer by the chunk's first entry
-    hipLaunchKernelGGL(k_band_select, dim3((unsigned)(u1 - u0)), blk, 0, nullptr, (const DPair*)dpairs.p + u0,
-                       (uint32_t*)hist.p - h_hbase[(size_t)u0], (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, bc,
+    hipLaunchKernelGGL(k_band_select, dim3((unsigned)(u1 - u0)), blk, 0, nullptr, (const DPair*)dpairs.p + u0, (uint32_t*)hist.p,
+                       (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, h_hbase[(size_t)u0], bc,
                        (pw_overlap_band*)dout.p + u0);
     u0 = u1;
   }
@@ -457,7 +463,6 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   float t = 0.f;
   OV_CHECK(hipEventElapsedTime(&t, ev0, ev1));
   *ms = t;
-  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   *n_out = (int64_t)NP;
   return 0;
 }
@@ -522,8 +527,9 @@ int pw_overlap_bands(int device, const uint8_t* arena, uint64_t arena_bytes, con
   Buf d_arena;
   if (d_arena.alloc((size_t)arena_bytes + 64)) return -1;
   OV_CHECK(hipMemcpy(d_arena.p, arena, (size_t)arena_bytes, hipMemcpyHostToDevice));
-  hipEvent_t ev0, ev1;
-  OV_CHECK(hipEventCreate(&ev0)); OV_CHECK(hipEventCreate(&ev1));
+  Ev e0, e1;
+  if (e0.make() || e1.make()) return -1;
+  const hipEvent_t ev0 = e0.e, ev1 = e1.e;
   // chunks: at most 2^31 histogram entries, 2^31 k-mers per side and pair ids that fit beside the k-mer
   const uint64_t lim = 1ull << 31;
   const int64_t max_pairs_bits = 62 - kbits;
@@ -541,7 +547,6 @@ int pw_overlap_bands(int device, const uint8_t* arena, uint64_t arena_bytes, con
                    BandConst{len_coeff, radius_coeff, word_p_null}, out + p0, ev0, ev1, &ms);
     p0 = p1;
   }
-  (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
   g_ms = (double)ms;
   return rc;
 }
