@@ -78,12 +78,25 @@ class Sequence(object):
         assert isinstance(alphabet, Alphabet)
         self.alphabet = alphabet
         if isinstance(contents, np.ndarray):
-            contents = contents.tolist()
-        contents = tuple(int(c) if isinstance(c, (np.integer,)) else c for c in contents)
-        assert all(isinstance(c, int) and 0 <= c < len(alphabet) for c in contents)
+            assert contents.ndim == 1 and (contents.dtype.kind in 'iu' or contents.size == 0)
+            assert contents.size == 0 or (0 <= int(contents.min()) and int(contents.max()) < len(alphabet))
+            contents = tuple(contents.tolist())
+        elif isinstance(contents, Sequence):
+            contents = contents.contents
+        else:
+            contents = tuple(int(c) if isinstance(c, (np.integer,)) else c for c in contents)
+            assert all(isinstance(c, int) and 0 <= c < len(alphabet) for c in contents)
         self.contents = contents
-        # reference: sha1(str(self)) (sequence.py:190); bytes are needed under Python 3
-        self.content_id = sha1(str(self).encode('utf-8')).hexdigest()
+
+    @property
+    def content_id(self):
+        """Hex SHA-1 of the printed sequence (reference ``sequence.py:190`` computes it in the constructor; here it is
+        computed on first use -- sequences of megabases are sliced often and compared rarely)."""
+        cid = self.__dict__.get('_content_id')
+        if cid is None:
+            cid = sha1(str(self).encode('utf-8')).hexdigest()
+            self.__dict__['_content_id'] = cid
+        return cid
 
     def as_array(self, dtype=np.uint8):
         """The contents as a numpy array (one byte per letter is what the device arena holds)."""
@@ -121,10 +134,14 @@ class Sequence(object):
     def __getitem__(self, key):
         if isinstance(key, (int, np.integer)):
             return self.contents[key]
-        return Sequence(self.alphabet, self.contents.__getitem__(key))
+        sub = Sequence.__new__(Sequence)                 # a slice of valid contents needs no re-validation
+        sub.alphabet = self.alphabet
+        sub.contents = self.contents.__getitem__(key)
+        return sub
 
     def __eq__(self, other):
-        return self.alphabet == other.alphabet and self.content_id == other.content_id
+        # the reference compares content ids (sequence.py:224-226); equal alphabets print equal contents equally
+        return self.alphabet == other.alphabet and self.contents == other.contents
 
     def __ne__(self, other):
         return not self.__eq__(other)
