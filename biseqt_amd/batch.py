@@ -41,6 +41,26 @@ class DeviceBuffer(object):
         return dict(shape=(self.nbytes,), typestr='|u1', data=(self.ptr, False), version=2)
 
 
+PAIR_DTYPE = np.dtype([('origin_off', '<u8'), ('mutant_off', '<u8'), ('origin_len', '<i4'), ('mutant_len', '<i4'),
+                       ('dmin', '<i4'), ('dmax', '<i4')])
+assert PAIR_DTYPE.itemsize == 32
+
+
+def pack_reads(reads):
+    """All reads once in one letter arena, every read on a 16-byte boundary (frames must be 4-byte aligned, with
+    slack behind): returns ``(arena uint8, offsets int64, lengths int32)`` for :meth:`BatchAligner.from_arena`."""
+    arrs = [_as_u8(r) for r in reads]
+    lens = np.array([len(a) for a in arrs], np.int64)
+    sizes = (lens + 15) // 16 * 16 + 16
+    offs = np.zeros(len(arrs), np.int64)
+    if len(arrs):
+        offs[1:] = np.cumsum(sizes)[:-1]
+    arena = np.zeros(int(sizes.sum()) + 16, np.uint8)
+    for a, o in zip(arrs, offs):
+        arena[o:o + len(a)] = a
+    return arena, offs, lens.astype(np.int32)
+
+
 class BatchAligner(object):
     """Plan, upload, solve and trace back a batch of pairs.
 
@@ -114,6 +134,53 @@ class BatchAligner(object):
             raise RuntimeError('pw_batch_create failed: ' + W.last_error())
         if kw.get('upload', True):
             self.upload()
+
+    @classmethod
+    def from_arena(cls, arena, offsets, lengths, pairs, diag_ranges=None, **kw):
+        """Pairs that REFER to reads of one shared arena (:func:`pack_reads`) instead of carrying copies: ``pairs`` is
+        an (n, 2) array of read indices (origin, mutant), ``diag_ranges`` an (n, 2) array in banded mode.  This is the
+        shape of overlap pipelines, where every read takes part in dozens of pairs."""
+        self = cls.__new__(cls)
+        self.lib = W.load()
+        self.alnmode = kw.get('alnmode', W.STD_MODE)
+        self.alntype = kw.get('alntype', W.GLOBAL)
+        pairs = np.ascontiguousarray(pairs, np.int64).reshape(-1, 2)
+        self.n = len(pairs)
+        L = kw['alphabet_len']
+        self.L = L
+        subst = kw.get('subst_scores')
+        if subst is None:
+            match, mismatch = kw.get('match_score', 1), kw.get('mismatch_score', 0)
+            subst = [[match if i == j else mismatch for i in range(L)] for j in range(L)]
+        self.subst_scores = subst
+        self.go_score, self.ge_score = kw.get('go_score', 0), kw.get('ge_score', 0)
+        offsets, lengths = np.asarray(offsets, np.int64), np.asarray(lengths, np.int64)
+        assert (offsets % 4 == 0).all(), 'reads must start on 4-byte boundaries'
+        rec = np.zeros(max(self.n, 1), PAIR_DTYPE)
+        rec['origin_off'][:self.n] = offsets[pairs[:, 0]]; rec['mutant_off'][:self.n] = offsets[pairs[:, 1]]
+        rec['origin_len'][:self.n] = lengths[pairs[:, 0]]; rec['mutant_len'][:self.n] = lengths[pairs[:, 1]]
+        if self.alnmode == W.BANDED_MODE:
+            dr = np.asarray(diag_ranges, np.int64).reshape(-1, 2)
+            assert len(dr) == self.n
+            if kw.get('check_band', True):
+                assert ((-rec['mutant_len'][:self.n] <= dr[:, 0]) & (dr[:, 0] <= dr[:, 1]) &
+                        (dr[:, 1] <= rec['origin_len'][:self.n])).all(), 'diag_range outside the table'
+            rec['dmin'][:self.n] = dr[:, 0]; rec['dmax'][:self.n] = dr[:, 1]
+        self._pairs = rec
+        self.arena = np.ascontiguousarray(arena, np.uint8)
+        self.lens = None
+        S = np.ascontiguousarray(np.asarray(subst, dtype=np.float64).reshape(L, L))
+        self._S = S
+        sc = W.pw_scoring(self.alnmode, self.alntype, L, S.ctypes.data_as(C.POINTER(C.c_double)),
+                          float(self.go_score), float(self.ge_score))
+        self.device = kw.get('device', 0)
+        self.flags = kw.get('flags', 0)
+        self.handle = self.lib.pw_batch_create(self.device, C.byref(sc), self.n, rec.ctypes.data_as(C.POINTER(W.pw_pair)),
+                                               self.arena.nbytes, self.flags)
+        if not self.handle:
+            raise RuntimeError('pw_batch_create failed: ' + W.last_error())
+        self.upload()
+        return self
 
     # ---- lifecycle ----
     def close(self):
@@ -213,6 +280,15 @@ class BatchAligner(object):
             end = off.value + cap.value
             out.append(buf[end - n:end].tobytes().decode('ascii'))
         return out
+
+    def transcript_slots(self):
+        """(offsets, capacities) of all transcript slots as arrays (ops of pair k END at offset + capacity)."""
+        off, cap = np.zeros(self.n, np.uint64), np.zeros(self.n, np.int32)
+        o, c = C.c_uint64(), C.c_int32()
+        for k in range(self.n):
+            self.lib.pw_batch_tx_slot(self.handle, k, C.byref(o), C.byref(c))
+            off[k], cap[k] = o.value, c.value
+        return off, cap
 
     def scores_plane(self, k):
         """Score of every cell of pair k as ``plane[d - dmin, a]`` (needs PW_FLAG_DUMP_SCORES)."""

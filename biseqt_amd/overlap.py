@@ -150,34 +150,47 @@ def overlap_all_pairs(reads, wordlen, alphabet, g_max, sensitivity, device=0, ma
     return dict(zip(plist, res))
 
 
-def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, **aligner_kw):
-    """Banded overlap alignment (``B_OVERLAP``) of every pair whose band has ``p >= p_min``, all in one batch; the
-    ``diag_range`` is the band clamped to the table as ``Aligner`` requires (``pw.py:224-226``).  Returns a list with
-    one entry per pair: None, or dict(score, transcript, origin_start, mutant_start, diag_range)."""
-    arrs = [r.as_array(np.uint8) if isinstance(r, Sequence) else np.ascontiguousarray(r, np.uint8) for r in reads]
-    sel, bp, dr = [], [], []
+def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, max_cells=2 * 10 ** 10, want_transcripts=True,
+                       **aligner_kw):
+    """Banded overlap alignment (``B_OVERLAP``) of every pair whose band has ``p >= p_min``; the ``diag_range`` is the
+    band clamped to the table as ``Aligner`` requires (``pw.py:224-226``).  All reads are uploaded ONCE and the pairs
+    refer to them (``BatchAligner.from_arena``); the pairs are solved in batches of at most ``max_cells`` cells
+    (tie masks take 0.5-0.6 bytes per cell of HBM).  ``bands`` is a list aligned with ``pairs`` (dicts or None).
+    Returns a list with one entry per pair: None, or dict(score, transcript, origin_start, mutant_start,
+    diag_range)."""
+    from .batch import pack_reads
+    arena, offs, lens = pack_reads(reads)
+    sel, dr = [], []
     for q, ((i, j), band) in enumerate(zip(pairs, bands)):
         if band is None or band['p'] < p_min:
             continue
-        lo = max(int(band['d_band'][0]), -len(arrs[j]))
-        hi = min(int(band['d_band'][1]), len(arrs[i]))
+        lo = max(int(band['d_band'][0]), -int(lens[j]))
+        hi = min(int(band['d_band'][1]), int(lens[i]))
         if lo > hi:
             continue
-        sel.append(q); bp.append((arrs[i], arrs[j])); dr.append((lo, hi))
+        sel.append(q); dr.append((lo, hi))
     out = [None] * len(pairs)
     if not sel:
         return out
     kw = dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
     kw.update(aligner_kw)
-    with BatchAligner(bp, alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP, alphabet_len=len(alphabet), diag_range=dr,
-                      device=device, **kw) as b:
-        res = b.run()
-        txs = b.transcripts(res)
-    for k, q in enumerate(sel):
-        if res['opt_i'][k] < 0:
-            continue
-        out[q] = dict(score=float(res['score'][k]), transcript=txs[k], origin_start=int(res['origin_idx'][k]),
-                      mutant_start=int(res['mutant_idx'][k]), diag_range=dr[k])
+    pidx = np.array([pairs[q] for q in sel], np.int64)
+    dr = np.array(dr, np.int64)
+    cells = (dr[:, 1] - dr[:, 0] + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
+    start = 0
+    while start < len(sel):
+        csum = np.cumsum(cells[start:])
+        stop = start + max(1, int(np.searchsorted(csum, max_cells, 'right')))
+        with BatchAligner.from_arena(arena, offs, lens, pidx[start:stop], dr[start:stop], alnmode=W.BANDED_MODE,
+                                     alntype=W.B_OVERLAP, alphabet_len=len(alphabet), device=device, **kw) as b:
+            res = b.run()
+            txs = b.transcripts(res) if want_transcripts else [None] * (stop - start)
+        for k in range(stop - start):
+            if res['opt_i'][k] < 0:
+                continue
+            out[sel[start + k]] = dict(score=float(res['score'][k]), transcript=txs[k], origin_start=int(res['origin_idx'][k]),
+                                       mutant_start=int(res['mutant_idx'][k]), diag_range=(int(dr[start + k, 0]), int(dr[start + k, 1])))
+        start = stop
     return out
 
 

@@ -44,22 +44,36 @@ def main():
           'true overlaps > 500 bases in the read set: %d' % (len(pairs), int(recs['n_seeds'].sum()), int(pos.sum()),
                                                             int((pos & (ov > 500)).sum()), int((pos & (ov <= 0)).sum()), true_total))
     print('  %.2f G pairs/s of the all-pairs space, %.2f M candidate pairs/s' % (R * (R - 1) / 2 / ms / 1e6, len(pairs) / ms / 1e3))
-    # banded overlap alignment (B_OVERLAP, 1/-3/-5/-2) of the first NA positive pairs in one batch
+    # banded overlap alignment (B_OVERLAP, 1/-3/-5/-2) of the positive pairs (the first NA of them; NA < 0: all), the
+    # reads uploaded once and referred to by the pairs, in batches of at most 2e10 cells
+    from biseqt_amd.batch import pack_reads
     NA = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
-    sel = np.flatnonzero(pos)[:NA]
-    bp = [(reads[pairs[q, 0]], reads[pairs[q, 1]]) for q in sel]
-    dr = [(max(int(recs['d_best'][q] - recs['r_best'][q]), -len(reads[pairs[q, 1]])),
-           min(int(recs['d_best'][q] + recs['r_best'][q]), len(reads[pairs[q, 0]]))) for q in sel]
+    sel = np.flatnonzero(pos)
+    if NA >= 0:
+        sel = sel[:NA]
     t4 = time.perf_counter()
-    with BatchAligner(bp, alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP, alphabet_len=4, diag_range=dr, match_score=1,
-                      mismatch_score=-3, go_score=-5, ge_score=-2, flags=W.PW_FLAG_PROFILE) as b:
-        t5 = time.perf_counter()
-        b.solve(); b.traceback(); b.sync()
-        b.solve(); b.traceback(); b.sync()
-        res = b.results()
-        print('  banded overlap alignment of %d pairs: planning + upload %.2f s; fill %.1f ms + traceback %.1f ms for %.3g cells = %.0f GCUPS (%s); '
-              'mean score %.0f' % (len(sel), t5 - t4, b.fill_ms(), b.trace_ms(), b.cells, b.cells / (b.fill_ms() + b.trace_ms()) / 1e6,
-                                   b.kernel_name, float(res['score'].mean())))
+    arena, offs, lens = pack_reads(reads)
+    pidx = pairs[sel].astype(np.int64)
+    lo = np.maximum(recs['d_best'][sel].astype(np.int64) - recs['r_best'][sel], -lens[pidx[:, 1]].astype(np.int64))
+    hi = np.minimum(recs['d_best'][sel].astype(np.int64) + recs['r_best'][sel], lens[pidx[:, 0]].astype(np.int64))
+    dr = np.stack([lo, hi], axis=1)
+    cells = (hi - lo + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
+    t5 = time.perf_counter()
+    start, dev_ms, tot_cells, nb, score_sum = 0, 0.0, 0, 0, 0.0
+    while start < len(sel):
+        stop = start + max(1, int(np.searchsorted(np.cumsum(cells[start:]), 2 * 10 ** 10, 'right')))
+        with BatchAligner.from_arena(arena, offs, lens, pidx[start:stop], dr[start:stop], alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP,
+                                     alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2,
+                                     flags=W.PW_FLAG_PROFILE) as b:
+            b.solve(); b.traceback(); b.sync()
+            res = b.results()
+            dev_ms += b.fill_ms() + b.trace_ms(); tot_cells += b.cells; nb += 1; score_sum += float(res['score'].sum())
+            kname = b.kernel_name
+        start = stop
+    t6 = time.perf_counter()
+    print('  banded overlap alignment of %d pairs in %d batches: %.3g cells, device %.1f ms = %.0f GCUPS (%s); wall %.2f s '
+          '(+ %.2f s packing the reads); mean score %.0f' % (len(sel), nb, tot_cells, dev_ms, tot_cells / dev_ms / 1e6, kname,
+                                                            t6 - t5, t5 - t4, score_sum / max(len(sel), 1)))
 
 
 if __name__ == '__main__':
