@@ -99,7 +99,7 @@ __device__ __forceinline__ double ov_x(int d, int ls, int lt, BandConst c) {
 // one workgroup per pair
 __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ pairs, uint32_t* hist,
                                                      const unsigned long long* __restrict__ nrows, const int32_t* __restrict__ d_first,
-                                                     uint64_t hist_first, BandConst c, pw_overlap_band* __restrict__ out) {
+                                                     uint64_t hist_first, int small_max, BandConst c, pw_overlap_band* __restrict__ out) {
   __shared__ uint32_t s_sum[256];
   __shared__ double s_w[256];
   __shared__ int s_d[256], s_cnt[256];
@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
   memset(&o, 0, sizeof o);
   o.n_seeds = (int64_t)nrows[p];
   if (o.n_seeds == 0) { if (tid == 0) out[p] = o; return; }
+  if (o.n_seeds <= small_max) return;                  // the sparse kernel (k_band_small) scores these
   // ---- inclusive prefix sums in place: every thread owns a contiguous chunk ----
   const int chunk = (nd + 255) / 256;
   const int b = tid * chunk, e = b + chunk < nd ? b + chunk : nd;
@@ -257,11 +258,14 @@ __global__ __launch_bounds__(256) void k_cand_pairs(const uint64_t* __restrict__
   d_first[u] = dval[soff[u]];
   pa[u] = (int32_t)a; pb[u] = (int32_t)b;
 }
-__global__ __launch_bounds__(256) void k_pair_hsize(const uint64_t* __restrict__ ukeys, int64_t np, uint64_t nreads,
-                                                    const int32_t* __restrict__ rlen, uint64_t* __restrict__ hsize) {
+constexpr int kSmallPair = 64;     // pairs with at most this many seeds are scored by one wavefront, without a histogram
+__global__ __launch_bounds__(256) void k_pair_hsize(const uint64_t* __restrict__ ukeys, const unsigned long long* __restrict__ cnt,
+                                                    int64_t np, uint64_t nreads, const int32_t* __restrict__ rlen,
+                                                    uint64_t* __restrict__ hsize) {
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (u >= np) return;
-  hsize[u] = (uint64_t)rlen[ukeys[u] / nreads] + (uint64_t)rlen[ukeys[u] % nreads] + 1;
+  hsize[u] = cnt[u] <= (unsigned long long)kSmallPair ? 0ull
+                                                      : (uint64_t)rlen[ukeys[u] / nreads] + (uint64_t)rlen[ukeys[u] % nreads] + 1;
 }
 // seeds [s0, s1) belong to the pairs [u0, u1) of this chunk; hbase is relative to the chunk's first histogram entry
 __global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict__ dval, int64_t s0, int64_t s1,
@@ -270,8 +274,67 @@ __global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict_
   const int64_t o = s0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= s1) return;
   const int64_t u = u0 + ub_u64(soff + u0, u1 - u0, (uint64_t)o) - 1;
+  if ((u + 1 < u1 ? soff[u + 1] : (uint64_t)s1) - soff[u] <= (uint64_t)kSmallPair) return;     // no histogram for small pairs
   const DPair pr = pairs[u];
   atomicAdd(&hist[pr.hbase - hchunk0 + (uint64_t)(dval[o] + pr.t_len)], 1u);
+}
+
+// K8d: a pair with at most 64 seeds is scored by ONE wavefront straight from its seed list (lane l = seed l, in table
+// order): same L, r, window, n, w as k_band_select's eval(), the neighbour count by a shuffle loop over the lanes.
+__global__ __launch_bounds__(256) void k_band_small(const DPair* __restrict__ pairs, const uint64_t* __restrict__ soff,
+                                                    const unsigned long long* __restrict__ cnt, const int32_t* __restrict__ dval,
+                                                    int64_t np, BandConst c, pw_overlap_band* __restrict__ out) {
+  const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int l = (int)(threadIdx.x & 63u);
+  if (u >= np) return;
+  const int ns = (int)(cnt[u] > 64ull ? 65 : cnt[u]);
+  if (ns > kSmallPair) return;
+  const DPair pr = pairs[u];
+  const int ls = pr.s_len, lt = pr.t_len;
+  const bool valid = l < ns;
+  const int d = valid ? dval[soff[u] + (uint64_t)l] : 0x7fffffff;
+  int L = 1, r = 1, first = 0, last = 0;
+  if (valid) {
+    L = ov_len(d, ls, lt, c.q); r = ov_rad(L, c.C);
+    const double x = (double)d / (double)r;
+    int lo = -lt, hi = d;
+    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (!(x - ov_x(mid, ls, lt, c) <= 1.0)) lo = mid + 1; else hi = mid; }
+    first = lo;
+    lo = d; hi = ls;
+    while (lo < hi) { const int mid = lo + ((hi - lo + 1) >> 1); if (ov_x(mid, ls, lt, c) - x <= 1.0) lo = mid; else hi = mid - 1; }
+    last = lo;
+  }
+  int n = -1; bool rep = valid;
+  for (int j = 0; j < ns; j++) {
+    const int dj = __shfl(d, j, 64);
+    n += (valid && dj >= first && dj <= last) ? 1 : 0;
+    rep = rep && !(j < l && dj == d);              // the first lane of every occupied diagonal represents it
+  }
+  const double w = valid ? ((double)(n + 1) - (double)(2ll * r * L) * c.p0) / (double)L : 0.0;
+  // best occupied diagonal: largest w, then smallest d
+  double bw = w; int bd = rep ? d : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double ow = __shfl_xor(bw, off, 64); const int od = __shfl_xor(bd, off, 64);
+    if (od != 0x7fffffff && (bd == 0x7fffffff || ow > bw || (ow == bw && od < bd))) { bw = ow; bd = od; }
+  }
+  const double wcap = bw >= 1.0 ? 1.0 : bw;
+  const double thr = wcap - fabs(wcap) * 1e-9;
+  const unsigned long long tie_mask = __ballot(rep && (bw <= 0.0 || w >= thr));
+  const unsigned long long win_mask = __ballot(rep && d == bd);
+  const int wl = __ffsll((long long)win_mask) - 1;
+  const int rb = __shfl(r, wl, 64), Lb = __shfl(L, wl, 64), nb = __shfl(n, wl, 64);
+  const int r0 = __shfl(r, 0, 64), L0 = __shfl(L, 0, 64), n0 = __shfl(n, 0, 64), d0 = __shfl(d, 0, 64);
+  const unsigned long long band_b = __ballot(valid && d >= bd - rb && d <= bd + rb);
+  const unsigned long long band_f = __ballot(valid && d >= d0 - r0 && d <= d0 + r0);
+  if (l == 0) {
+    pw_overlap_band o;
+    memset(&o, 0, sizeof o);
+    o.n_seeds = ns; o.w_best = bw; o.d_best = bd; o.n_best = nb; o.r_best = rb; o.len_best = Lb;
+    o.band_best = __popcll(band_b); o.tie = __popcll(tie_mask);
+    o.d_first = d0; o.n_first = n0; o.r_first = r0; o.len_first = L0; o.band_first = __popcll(band_f);
+    out[u] = o;
+  }
 }
 
 struct Ev {
@@ -335,7 +398,7 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
                      (const uint64_t*)ksb.p, (const uint32_t*)psb.p, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
                      (int32_t*)dfirst.p);
   hipLaunchKernelGGL(k_band_select, dim3((unsigned)n), dim3(256), 0, nullptr, (const DPair*)dp.p, (uint32_t*)hist.p,
-                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, (uint64_t)0, bc, (pw_overlap_band*)dout.p);
+                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, (uint64_t)0, 0, bc, (pw_overlap_band*)dout.p);
   OV_CHECK(hipEventRecord(ev1, nullptr));
   OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)n, hipMemcpyDeviceToHost));
   OV_CHECK(hipGetLastError());
@@ -429,11 +492,14 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   Buf tmp5;
   if (tmp5.alloc(tb5)) return -1;
   OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)uc.p, (uint64_t*)soff.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
-  hipLaunchKernelGGL(k_pair_hsize, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (int64_t)NP, (uint64_t)R, (const int32_t*)drlen.p, (uint64_t*)hsize.p);
+  hipLaunchKernelGGL(k_pair_hsize, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (const unsigned long long*)uc.p, (int64_t)NP, (uint64_t)R,
+                     (const int32_t*)drlen.p, (uint64_t*)hsize.p);
   OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)hsize.p, (uint64_t*)hbase.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
   hipLaunchKernelGGL(k_cand_pairs, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (const uint64_t*)soff.p, (const int32_t*)dv.p, (int64_t)NP, (uint64_t)R,
                      (const uint64_t*)droff.p, (const int32_t*)drlen.p, (const uint64_t*)hbase.p, (DPair*)dpairs.p, (int32_t*)dfirst.p,
                      (int32_t*)dpa.p, (int32_t*)dpb.p);
+  hipLaunchKernelGGL(k_band_small, dim3((unsigned)((NP * 64 + 255) / 256)), blk, 0, nullptr, (const DPair*)dpairs.p, (const uint64_t*)soff.p,
+                     (const unsigned long long*)uc.p, (const int32_t*)dv.p, (int64_t)NP, bc, (pw_overlap_band*)dout.p);
   // chunks of pairs whose histograms fit 2^30 counters
   std::vector<uint64_t> h_hbase((size_t)NP), h_soff((size_t)NP), h_hsize((size_t)NP);
   OV_CHECK(hipMemcpy(h_hbase.data(), hbase.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
@@ -451,7 +517,7 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
     hipLaunchKernelGGL(k_scatter_hist, dim3((unsigned)((s1 - s0 + 255) / 256)), blk, 0, nullptr, (const int32_t*)dv.p, (int64_t)s0, (int64_t)s1,
                        (const uint64_t*)soff.p, (int64_t)u0, (int64_t)u1, (const DPair*)dpairs.p, h_hbase[(size_t)u0], (uint32_t*)hist.p);
     hipLaunchKernelGGL(k_band_select, dim3((unsigned)(u1 - u0)), blk, 0, nullptr, (const DPair*)dpairs.p + u0, (uint32_t*)hist.p,
-                       (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, h_hbase[(size_t)u0], bc,
+                       (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, h_hbase[(size_t)u0], kSmallPair, bc,
                        (pw_overlap_band*)dout.p + u0);
     u0 = u1;
   }

@@ -71,8 +71,9 @@ def main():
             kname = b.kernel_name
         start = stop
     t6 = time.perf_counter()
-    print('  banded overlap alignment of %d pairs in %d batches: %.3g cells, device %.1f ms = %.0f GCUPS (%s); wall %.2f s '
-          '(+ %.2f s packing the reads); mean score %.0f' % (len(sel), nb, tot_cells, dev_ms, tot_cells / dev_ms / 1e6, kname,
+    if len(sel):
+        print('  banded overlap alignment of %d pairs in %d batches: %.3g cells, device %.1f ms = %.0f GCUPS (%s); wall %.2f s '
+              '(+ %.2f s packing the reads); mean score %.0f' % (len(sel), nb, tot_cells, dev_ms, tot_cells / dev_ms / 1e6, kname,
                                                             t6 - t5, t5 - t4, score_sum / max(len(sel), 1)))
 
 
