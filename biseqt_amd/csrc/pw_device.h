@@ -151,10 +151,10 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
 }
 
 // Lane-packed 16-bit kernel: one wavefront = WaveDesc.count pairs side by side (pw_wave.h, WaveFill16).
-template <int BK, bool SEG>
+template <int BK, bool SEG, int RULE>
 __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int32_t> a) {
   const WaveDesc wd = a.waves[blockIdx.x];
-  WaveFill16<DevP, BK, SEG> w(a, wd);
+  WaveFill16<DevP, BK, SEG, RULE> w(a, wd);
   w.run();
 }
 

@@ -13,7 +13,7 @@ enum { VAR_FAST_ANY_TRACK = 0,  // begin anywhere + per-diagonal best: LOCAL, B_
        VAR_FAST_TRACK = 1,      // begin at origin/edges + per-diagonal best: START_ANCHORED
        VAR_FAST = 2,            // begin at origin/edges, end on the table edge: GLOBAL, *OVERLAP, B_GLOBAL, B_OVERLAP
        VAR_GENERIC = 3,         // substitution matrix / go > 0 / score-plane dump: everything at run time
-       VAR_FAST16 = 4 };        // LOCAL / B_LOCAL in packed 16-bit, several pairs per wavefront (launch_fill16)
+       VAR_FAST16 = 4 };        // packed 16-bit (LOCAL / B_LOCAL, B_OVERLAP, B_GLOBAL), several pairs per wavefront (launch_fill16)
 
 static const int kSupportedBK[] = {2, 4, 8, 16, 32};
 static const int kNumSupportedBK = 5;
@@ -24,7 +24,7 @@ hipError_t launch_fill(const FillParams<double>& a, int variant, int bk, int nbl
 static const int kPackedBK[] = {4, 8, 12, 16, 20, 24, 28, 32};
 static const int kNumPackedBK = 8;
 // seg != 0: several pairs per wavefront (WaveDesc.nl lanes each); seg == 0: one pair per wavefront, WaveDesc.nl == 64
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st);
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int nwaves, hipStream_t st);
 // wide bands: one workgroup of nw wavefronts (2048 diagonals each, nw <= kMaxWavesPerPair) per pair
 static const int kMaxWavesPerPair = 8;
 hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int bk, int nw, int nblocks, hipStream_t st);

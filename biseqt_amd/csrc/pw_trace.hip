@@ -85,8 +85,10 @@ hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
 PW_DECL(i32, int32_t)
 PW_DECL(f64, double)
 #undef PW_DECL
-#define PW_DECL16(BK) hipError_t launch_fill16_bk##BK(const FillParams<int32_t>&, int, int, hipStream_t);
-PW_DECL16(4) PW_DECL16(8) PW_DECL16(12) PW_DECL16(16) PW_DECL16(20) PW_DECL16(24) PW_DECL16(28) PW_DECL16(32)
+#define PW_DECL16(BK, R) hipError_t launch_fill16_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t);
+PW_DECL16(4, 0) PW_DECL16(8, 0) PW_DECL16(12, 0) PW_DECL16(16, 0) PW_DECL16(20, 0) PW_DECL16(24, 0) PW_DECL16(28, 0) PW_DECL16(32, 0)
+PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1)
+PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2)
 #undef PW_DECL16
 
 hipError_t launch_tile_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
@@ -107,18 +109,15 @@ hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int bk, int 
   return launch_fill_mw_f64(a, variant, bk, nw, nblocks, st);
 }
 
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int nwaves, hipStream_t st) {
-  switch (bk) {
-    case 4: return launch_fill16_bk4(a, seg, nwaves, st);
-    case 8: return launch_fill16_bk8(a, seg, nwaves, st);
-    case 12: return launch_fill16_bk12(a, seg, nwaves, st);
-    case 16: return launch_fill16_bk16(a, seg, nwaves, st);
-    case 20: return launch_fill16_bk20(a, seg, nwaves, st);
-    case 24: return launch_fill16_bk24(a, seg, nwaves, st);
-    case 28: return launch_fill16_bk28(a, seg, nwaves, st);
-    case 32: return launch_fill16_bk32(a, seg, nwaves, st);
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int nwaves, hipStream_t st) {
+#define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16_bk##BK##_r##R(a, seg, nwaves, st);
+  switch (bk * 4 + rule) {
+    PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
+    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1)
+    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2)
     default: return hipErrorInvalidValue;
   }
+#undef PW_CASE16
 }
 
 hipError_t launch_fill(const FillParams<int32_t>& a, int variant, int bk, int nblocks, hipStream_t st) {

@@ -574,6 +574,7 @@ PW_FN uint32_t max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t,
 // hazard recogniser.  Callers therefore pass the constants in registers made opaque once (pk::opaque).
 PW_FN uint32_t minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_u2(a), as_u2(b))); }
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) * as_u2(b) + as_u2(c))); }
+PW_FN uint32_t mins(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_s2(a), as_s2(b))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
 // sign mask per half (0xffff where negative): arithmetic shift by sh15 = (15, 15) held in an opaque register
 PW_FN uint32_t sign(uint32_t a, uint32_t sh15) { return __builtin_bit_cast(uint32_t, (s2_t)(as_s2(a) >> as_s2(sh15))); }
@@ -592,6 +593,7 @@ PW_FN uint32_t minu(uint32_t a, uint32_t b) {
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) {
   return mk((uint32_t)(sl(a) * sl(b) + sl(c)), (uint32_t)(sh(a) * sh(b) + sh(c)));
 }
+PW_FN uint32_t mins(uint32_t a, uint32_t b) { return mk((uint32_t)(sl(a) < sl(b) ? sl(a) : sl(b)), (uint32_t)(sh(a) < sh(b) ? sh(a) : sh(b))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 PW_FN uint32_t sign(uint32_t a, uint32_t) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
 PW_FN uint32_t opaque(uint32_t v) { return v; }
@@ -602,13 +604,22 @@ PW_FN int32_t lo_s(uint32_t v) { return (int32_t)(int16_t)(v & 0xffffu); }
 PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 }  // namespace pk
 
-template <class P, int BK, bool SEG>
+// RULE selects the begin / end rules the kernel serves:
+//   0  LOCAL / B_LOCAL            begin anywhere (B = 0 in every started cell), end = first best cell (tracked)
+//   1  B_OVERLAP                  begin on the table edge (B = 0 only in the FIRST cell of a diagonal), end = the best
+//                                 LAST cell of a diagonal
+//   2  B_GLOBAL                   begin at (0, 0) only, end = cell (X, Y)
+// Rules 1 and 2 have negative scores, so their sentinel is deeper (-24000; real scores stay within +-15000, see the
+// host planner), the first diagonal above the band is silenced by clamping its offer (adding a second sentinel to a
+// real score could wrap), every cell takes max(.., sentinel) -- which also pins cells before a diagonal's start and
+// beyond its end -- and instead of tracking a best the value of each diagonal's last cell is captured.
+template <class P, int BK, bool SEG, int RULE = 0>
 struct WaveFill16 {
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
   static constexpr int UNR = BK <= 8 ? 4 : (BK <= 16 ? 2 : 1);   // iterations unrolled per loop trip
-  static constexpr int32_t NEG16 = -8192;
+  static constexpr int32_t NEG16 = RULE == 0 ? -8192 : -24000;
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
   using Base = WaveFill<P, int32_t, BK, true, true, false>;       // only its static feeder helpers are used
 
@@ -633,6 +644,7 @@ struct WaveFill16 {
   uint32_t HE[RH], UE[RH], LE[RH], HO[RH], UO[RH], LO[RH];
   uint32_t bestE[RH], bestO[RH], btE[RH], btO[RH];     // running best and the step it was first reached
   uint32_t gebE[RH], gebO[RH];                          // ge (+ the band-top block) per half
+  uint32_t clE[RH], clO[RH];                            // RULE != 0: clamp of the "left" offer (sentinel for the slot above the band)
   uint32_t tfE[RH], tfO[RH], tlE[RH], tlO[RH];          // first / last step of each diagonal
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
@@ -653,29 +665,46 @@ struct WaveFill16 {
   //   * a diagonal that has ended keeps computing cells beyond the table; nothing in the table reads them
   //     (predecessors have smaller coordinates), their tie nibbles land in mask slots the walker never
   //     visits, and they are kept out of the running best by lowering them by 32767 first.
+  // For RULE != 0: `bests` holds the captured value of the diagonal's LAST cell, `bts` is unused, `tf` is the step of
+  // the one cell that may begin an alignment (32767 = none), `geb` is ge in both halves and `clampL` silences the
+  // first diagonal above the band.
   template <bool EDGE>
   PW_FN void cellpair(uint32_t& Hs, uint32_t& Us, uint32_t& Ls, uint32_t& bests, uint32_t& bts, uint32_t geb,
                       uint32_t tf, uint32_t tl, uint32_t& acc, uint32_t up, uint32_t left, uint32_t oc,
-                      uint32_t mc, uint32_t tv) {
+                      uint32_t mc, uint32_t tv, uint32_t clampL = 0) {
     const uint32_t ne = pk::minu(oc ^ mc, ONE);                 // 0 where the letters match
     const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
     uint32_t Hn = pk::max(pk::max(up, left), hM);
-    if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
-    else Hn = pk::max(Hn, 0u);                                   // B: an alignment may begin anywhere, score 0
+    uint32_t nB;
+    if (RULE == 0) {
+      if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
+      else Hn = pk::max(Hn, 0u);                                 // B: an alignment may begin anywhere, score 0
+      nB = pk::minu(Hn, ONE);
+    } else {
+      // B = 0 in the one cell that may begin (step tf), the sentinel everywhere else
+      const uint32_t Bc = EDGE ? pk::mad(pk::minu(tv ^ tf, ONE), NEGV, 0u) : NEGV;
+      Hn = pk::max(Hn, Bc);
+      nB = pk::minu(Hn ^ Bc, ONE);
+    }
     // "is the candidate kept" only asks whether H == candidate: xor (a 2-cycle op) instead of a packed subtract
     const uint32_t nD = pk::minu(Hn ^ up, ONE);
     const uint32_t nI = pk::minu(Hn ^ left, ONE);
-    const uint32_t nB = pk::minu(Hn, ONE);
     const uint32_t hg = pk::add(Hn, geb);
     Us = pk::mad(nD, GOV, hg);                                   // (H + ge) + go unless a D choice is kept
     Ls = pk::mad(nI, GOV, hg);
+    if (RULE != 0) Ls = pk::mins(Ls, clampL);
     // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
     acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
-    const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV) : Hn;
-    const uint32_t bn = pk::max(bests, Ht);
-    const uint32_t u = pk::minu(bn ^ bests, ONE);               // 1 where the best strictly improved
-    bts = pk::mad(u, tv - bts, bts);                             // steps only grow: no borrow between the halves
-    bests = bn;
+    if (RULE == 0) {
+      const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV) : Hn;
+      const uint32_t bn = pk::max(bests, Ht);
+      const uint32_t u = pk::minu(bn ^ bests, ONE);             // 1 where the best strictly improved
+      bts = pk::mad(u, tv - bts, bts);                           // steps only grow: no borrow between the halves
+      bests = bn;
+    } else if (EDGE) {
+      const uint32_t e = pk::minu(tv ^ tl, ONE);                 // 0 in the diagonal's last cell
+      bests = pk::mad(e, pk::sub(bests, Hn), Hn);                // e ? bests : Hn
+    }
     Hs = Hn;
   }
 
@@ -691,7 +720,7 @@ struct WaveFill16 {
 #pragma unroll
       for (int p = 0; p < RH; p++)
         cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
-                       p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0);
+                       p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
     // Only cells outside the table read letters outside a sequence; in steady blocks those are out-of-band
@@ -715,7 +744,7 @@ struct WaveFill16 {
 #pragma unroll
       for (int p = 0; p < RH; p++)
         cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
-                       UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1);
+                       UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
     }
     // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
     {
@@ -789,6 +818,12 @@ struct WaveFill16 {
     const int len = 1 + (d > 0 ? 0 : d) + (X - d > Y ? Y : X - d);
     return (d < 0 ? -d : d) - pd.s0 + 2 * (len - 1);
   }
+  PW_FN int tbegin_of(int j) const {      // RULE != 0: the step of the diagonal's cell that may begin an alignment
+    const int dd = li * BK + j, d = pd.dmin + dd;
+    if (!valid || dd >= ndiag) return 32767;
+    if (RULE == 2 && d != 0) return 32767;                 // B_GLOBAL: cell (0, 0) only
+    return (d < 0 ? -d : d) - pd.s0;                       // the first cell of the diagonal lies on the table edge
+  }
   PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)X ? (uint32_t)oseq[i] : SENT_O; }
   PW_FN uint32_t letter_m(int i) const { return (uint32_t)i < (uint32_t)Y ? (uint32_t)mseq[i] : SENT_M; }
   PW_FN int blocked(int j) const { return li * BK + j == ndiag ? NEG16 : 0; }   // first diagonal above the band
@@ -819,9 +854,17 @@ struct WaveFill16 {
 #pragma unroll
     for (int p = 0; p < RH; p++) {
       const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      gebE[p] = pk::pack(a.ge + blocked(e0), a.ge + blocked(e1));
-      gebO[p] = pk::pack(a.ge + blocked(o0), a.ge + blocked(o1));
-      tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
+      if (RULE == 0) {
+        gebE[p] = pk::pack(a.ge + blocked(e0), a.ge + blocked(e1));
+        gebO[p] = pk::pack(a.ge + blocked(o0), a.ge + blocked(o1));
+        tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
+        clE[p] = clO[p] = 0;
+      } else {
+        gebE[p] = gebO[p] = pk::both(a.ge);
+        clE[p] = pk::pack(blocked(e0) ? NEG16 : 32767, blocked(e1) ? NEG16 : 32767);
+        clO[p] = pk::pack(blocked(o0) ? NEG16 : 32767, blocked(o1) ? NEG16 : 32767);
+        tfE[p] = pk::pack(tbegin_of(e0), tbegin_of(e1)); tfO[p] = pk::pack(tbegin_of(o0), tbegin_of(o1));
+      }
       tlE[p] = pk::pack(tlast_of(e0), tlast_of(e1)); tlO[p] = pk::pack(tlast_of(o0), tlast_of(o1));
       HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
       bestE[p] = bestO[p] = NEGV; btE[p] = btO[p] = 0;
@@ -842,7 +885,7 @@ struct WaveFill16 {
   // cell of every in-band diagonal, reduced on (score desc, scan rank asc) -- once per pair of the wave.
   PW_FN void finish() {
     const int endrule = a.endrule;
-    int32_t cs = NEG16 - 1; uint64_t ck = ~(uint64_t)0; int cx = -1, cy = -1; bool have = false;
+    int32_t cs = -32768; uint64_t ck = ~(uint64_t)0; int cx = -1, cy = -1; bool have = false;
     // Runs once per pair: keep it out of the register budget of the fill loop.  The packed bests are parked
     // in a small private array and scanned by a rolled loop.
     uint32_t parked[4 * RH];
@@ -862,11 +905,18 @@ struct WaveFill16 {
         const int bt = (int)(h ? (tq >> 16) : (tq & 0xffffu));
         const int tfirst = (d < 0 ? -d : d) - pd.s0;
         const int aa = (bt - tfirst) >> 1;
-        const int x = aa + (d > 0 ? d : 0), y = aa - (d < 0 ? d : 0);
+        int x = aa + (d > 0 ? d : 0), y = aa - (d < 0 ? d : 0);
         uint64_t k;
-        if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
+        bool ok = true;
+        if (RULE != 0) {
+          // `s` is the captured value of the diagonal's last cell (_banded_find_optimal, _pw_internals.c:364-414)
+          const bool ends_right = d < X - Y;
+          x = ends_right ? d + Y : X; y = ends_right ? Y : X - d;
+          k = (uint64_t)(uint32_t)dd;
+          if (RULE == 2) ok = d == X - Y;
+        } else if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
         else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
-        const bool better = valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));
+        const bool better = ok && valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));
         if (better) { cs = s; ck = k; cx = x; cy = y; have = true; }
       }
     }

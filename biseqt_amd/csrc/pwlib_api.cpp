@@ -66,7 +66,7 @@ struct pw_batch {
   std::vector<int32_t> tiled;           // pairs that go through the time-blocked tiled kernel (K2b)
   void* d_state[2] = {nullptr, nullptr}; // their per-diagonal state, double buffered (shared: pairs run one after another)
   int32_t st_pitch = 0;
-  int packed_seg = 0;
+  int packed_seg = 0, packed_rule = 0;
   pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
   // device
@@ -174,10 +174,21 @@ int batch_build(pw_batch* b) {
   // score bound is 8000, not 16000: the first diagonal above the band is computed like any other and its offer
   // into the band is lowered by only 8192 (the sentinel), so no score -- in or out of the band -- may reach that
   // (regression: test_band_edge_never_leaks_long_pairs).
-  int pbk = 0, pnl = 0, pseg = 0;
-  if (b->variant == pw::VAR_FAST_ANY_TRACK && track && !b->use_f64 &&
+  // Rules 1 / 2 (B_OVERLAP / B_GLOBAL, WaveFill16<.., RULE>): scores go negative, the sentinel is -24000 and every
+  // real score must stay within +-15000.  Lower bound of any in-band cell: the straight run down its own diagonal
+  // from the table edge (min(X,Y) substitutions) -- for B_GLOBAL after the gap run from (0, 0) to that diagonal.
+  int pbk = 0, pnl = 0, pseg = 0, prule = -1;
+  if (b->variant == pw::VAR_FAST_ANY_TRACK && track) prule = 0;
+  else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_EDGE && b->endrule == pw::END_BANDED_OVERLAP) prule = 1;
+  else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
+  bool pfits = false;
+  if (prule == 0) pfits = (double)maxmin * std::max(mt, 0.0) <= 8000;
+  else if (prule > 0)
+    pfits = (double)maxmin * std::max(fabs(mt), fabs(mm)) + fabs(b->go) + fabs(b->ge) * (maxnd + 2) <= 15000 && b->go <= 0 &&
+            maxnd <= 64 * 20 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
+  if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED)) && maxnd <= 2048 &&
-      nsolv > 0 && maxabs <= 100 && (double)maxmin * std::max(mt, 0.0) <= 8000 && maxspan < 32000 && b->ge <= 0) {
+      nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0) {
     // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
     // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
     // 64 x BK diagonal slots busy.  Packing is chosen when it buys at least 25 % more busy slots.
@@ -187,6 +198,7 @@ int batch_build(pw_batch* b) {
     double util1 = -1, utilp = -1; int bk1 = 0, bkp = 0, nlp = 0;
     for (int i = 0; i < pw::kNumPackedBK; i++) {
       const int bk = pw::kPackedBK[i];
+      if (prule > 0 && bk > 20) continue;                  // rules 1 / 2 are built for BK <= 20
       if (forced && atoi(forced) != bk) continue;
       const int nl = (maxnd + bk - 1) / bk;
       if (nl > 64) continue;
@@ -251,7 +263,7 @@ int batch_build(pw_batch* b) {
   if (b->variant == pw::VAR_FAST16) {
     // consecutive (similar length) pairs share a wavefront
     const int ppw = pseg ? 64 / pnl : 1;
-    b->packed_seg = pseg;
+    b->packed_seg = pseg; b->packed_rule = prule;
     BkClass& c = b->classes[0];
     for (size_t i = 0; i < c.order.size(); i += ppw) {
       pw::WaveDesc wd;
@@ -355,7 +367,7 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
   a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
   a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
   a.order = b->classes[0].d_order; a.waves = b->d_waves;
-  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, (int)b->waves.size(), st));
+  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, (int)b->waves.size(), st));
   return 0;
 }
 
@@ -416,7 +428,10 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   const char* t = b->use_f64 ? "double" : "int";
   if (nw > 1) { snprintf(name, sizeof name, "k_fill_mw<%s, %d, ...> x %d wavefronts", t, bk, nw); return name; }
   switch (b->variant) {
-    case pw::VAR_FAST16: snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false"); break;
+    case pw::VAR_FAST16:
+      if (b->packed_rule) snprintf(name, sizeof name, "k_fill16<%d, %s, %d>", bk, b->packed_seg ? "true" : "false", b->packed_rule);
+      else snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false");
+      break;
     case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;
     case pw::VAR_FAST_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, false, true, false>", t, bk); break;
     case pw::VAR_FAST: snprintf(name, sizeof name, "k_fill<%s, %d, false, false, false>", t, bk); break;

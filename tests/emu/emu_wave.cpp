@@ -113,8 +113,17 @@ template <int BK> struct Run16<int32_t, BK> {
       const bool seg = g_packed_mode == 1;
       wd.nl = seg ? pd.nl : 64;
       Emu emu;
-      if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true> w(a, wd); w.run(); });
-      else emu.run([&]() { pw::WaveFill16<EmuP, BK, false> w(a, wd); w.run(); });
+      const int rule = a.endrule == pw::END_BANDED_OVERLAP ? 1 : (a.endrule == pw::END_CORNER ? 2 : 0);
+      if (rule == 0) {
+        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 0> w(a, wd); w.run(); });
+        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 0> w(a, wd); w.run(); });
+      } else if (rule == 1) {
+        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 1> w(a, wd); w.run(); });
+        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 1> w(a, wd); w.run(); });
+      } else {
+        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 2> w(a, wd); w.run(); });
+        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 2> w(a, wd); w.run(); });
+      }
       return true;
     } else {
       return false;
@@ -177,7 +186,10 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   const int generic = force_generic || !simple || go > 0 || hdump != nullptr;
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
-  const int use16 = packed16 && !generic && bany && track && bk % 4 == 0 && sizeof(T) == 4;
+  const bool rule_local = bany && track;
+  const bool rule_overlap = mode == pw::BANDED_MODE && pl.brule == pw::BRULE_EDGE && pl.endrule == pw::END_BANDED_OVERLAP;
+  const bool rule_global = mode == pw::BANDED_MODE && pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_CORNER;
+  const int use16 = packed16 && !generic && (rule_local || rule_overlap || rule_global) && bk % 4 == 0 && sizeof(T) == 4;
   g_packed_mode = packed16;
   if (use16) pd.nl = (pl.ndiag + bk - 1) / bk;
   switch (bk) {

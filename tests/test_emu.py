@@ -117,3 +117,43 @@ def test_emu_packed16_local(oracle):
             assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
         n += 1
     assert n > 50
+
+
+def test_emu_packed16_overlap_and_global(oracle):
+    """The packed 16-bit kernel body with the overlap / global rules (WaveFill16<.., RULE = 1 | 2>: deeper sentinel,
+    clamped band-top offer, begin only in a diagonal's first cell / at (0, 0), captured last cells) against the
+    oracle: negative scores, clamped and infeasible bands, every supported BK, both lane layouts."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(17)
+    n = 0
+    for trial in range(120):
+        L = int(rng.choice([2, 4]))
+        X = int(rng.integers(0, 260)) if trial % 5 else int(rng.integers(0, 12))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        kind = trial % 3
+        if kind == 0:
+            m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 9))).astype(np.uint8)
+        elif kind == 1:                                     # suffix of o = prefix of m
+            k = int(rng.integers(0, X + 1))
+            m = np.concatenate([o[k:], rng.integers(0, L, int(rng.integers(0, 60))).astype(np.uint8)])
+        else:                                               # unrelated: scores go far below zero
+            m = rng.integers(0, L, int(rng.integers(0, 260))).astype(np.uint8)
+        kw = dict(L=L, match=float(rng.choice([1, 2, 5])), mismatch=float(rng.choice([0, -1, -3])),
+                  go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
+        alntype = 2 if trial % 2 else 0                     # B_OVERLAP / B_GLOBAL
+        r, c = int(rng.integers(0, 50)), int(rng.integers(-10, 10))
+        if alntype == 0 and rng.random() < 0.8:             # make the global band feasible most of the time
+            lo, hi = min(0, X - len(m)) - int(rng.integers(0, 20)), max(0, X - len(m)) + int(rng.integers(0, 20))
+        else:
+            lo, hi = c - r, c + r
+        kw.update(mode=1, alntype=alntype, diag_range=(lo, hi))
+        nd = min(hi, X) - max(lo, -len(m)) + 1
+        bk = next((b for b in (4, 8, 16, 32) if b >= (4, 8, 16)[trial % 3] and 64 * b >= nd), None)
+        if bk is None:
+            continue
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=bk, packed16=1 + trial % 2, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
+        n += 1
+    assert n > 90

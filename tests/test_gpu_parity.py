@@ -539,7 +539,10 @@ def test_wide_pairs_single_wavefront_and_latency_mode(oracle, latency_mode, monk
             res = b.run()
             txs = b.transcripts(res)
         ndiag = (band[1] - band[0] + 1) if band is not None else len(o) + len(m) + 1
-        assert ('k_fill_mw' in name) == (latency_mode == '1' and ndiag > 512), (name, ndiag)
+        if latency_mode == '0':
+            assert 'k_fill_mw' not in name, name
+        elif ndiag > 1024:                       # (up to 64 x 12 diagonals the packed one-wavefront kernel may still win)
+            assert 'k_fill_mw' in name, (name, ndiag)
         r = oracle.solve(o, m, **okw)
         assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'], (n, mode, alntype, name)
         if r['opt'][0] != -1:
@@ -547,3 +550,40 @@ def test_wide_pairs_single_wavefront_and_latency_mode(oracle, latency_mode, monk
             if not r['would_panick'] and not r['tb_null']:
                 assert txs[0] == r['transcript']
                 assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def test_packed_overlap_and_global_kernels_at_their_bounds(oracle):
+    """The 16-bit kernels for B_OVERLAP / B_GLOBAL (WaveFill16<.., RULE = 1 | 2>) where their arithmetic is tightest:
+    unrelated 4900-base pairs (scores near -15000, the sentinel is -24000), identical pairs with match 3 (+14700),
+    the true alignment lying on the first diagonal OUTSIDE the band (its offer must be clamped away), bands whose
+    width is not a multiple of the lane width, lane-packed and one-pair-per-wave layouts."""
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(2026)
+    a = synth.rand_seqs(rng, 1, 4900)[0]
+    b_ = synth.rand_seqs(rng, 1, 4900)[0]
+    near = synth.mutate(rng, a, .03, .01, .3)
+    cases = []
+    for alntype in (2, 0):                                   # B_OVERLAP, B_GLOBAL
+        cases += [
+            (a, b_, alntype, (-21, 20), dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)),      # unrelated
+            (a, a.copy(), alntype, (-7, 9), dict(match_score=3, mismatch_score=-3, go_score=-5, ge_score=-2)),   # +14700
+            (a, a.copy(), alntype, (-21, -1) if alntype == 2 else (-21, 0), dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)),
+            (a, a.copy(), alntype, (1, 23) if alntype == 2 else (0, 23), dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)),
+            (a, near, alntype, (min(0, len(a) - len(near)) - 37, max(0, len(a) - len(near)) + 41), dict(match_score=2, mismatch_score=-1, go_score=0, ge_score=-1)),
+        ]
+    for o, m, alntype, band, sc in cases:
+        for n in (1, 300):                                   # latency layout / throughput layout (lane packing)
+            with BatchAligner([(o, m)] * n, alnmode=1, alntype=alntype, alphabet_len=4, diag_range=band, **sc) as bt:
+                name = bt.kernel_name
+                res = bt.run()
+                txs = bt.transcripts(res)
+            assert 'k_fill16' in name and name.endswith(', %d>' % (1 if alntype == 2 else 2)), name
+            r = oracle.solve(o, m, L=4, mode=1, alntype=alntype, diag_range=band, match=sc['match_score'],
+                             mismatch=sc['mismatch_score'], go=sc['go_score'], ge=sc['ge_score'])
+            for k in (0, n - 1):
+                assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (alntype, band, name)
+                assert res['score'][k] == r['score'], (alntype, band, name, res['score'][k], r['score'])
+                if not r['would_panick'] and not r['tb_null']:
+                    assert txs[k] == r['transcript']
+                    assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
