@@ -609,8 +609,8 @@ PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 //   1  B_OVERLAP                  begin on the table edge (B = 0 only in the FIRST cell of a diagonal), end = the best
 //                                 LAST cell of a diagonal
 //   2  B_GLOBAL                   begin at (0, 0) only, end = cell (X, Y)
-// Rules 1 and 2 have negative scores, so their sentinel is deeper (-24000; real scores stay within +-15000, see the
-// host planner), the first diagonal above the band is silenced by clamping its offer (adding a second sentinel to a
+// Rules 1 and 2 have negative scores, so their sentinel is deeper (-24000; real scores stay within [-23000, 30000],
+// see the host planner), the first diagonal above the band is silenced by clamping its offer (adding a second sentinel to a
 // real score could wrap), every cell takes max(.., sentinel) -- which also pins cells before a diagonal's start and
 // beyond its end -- and instead of tracking a best the value of each diagonal's last cell is captured.
 template <class P, int BK, bool SEG, int RULE = 0>
@@ -871,11 +871,14 @@ struct WaveFill16 {
       OW[p] = pk::pack((int32_t)letter_o(xbase + p - 1), (int32_t)letter_o(xbase + p + RH - 1));
       MW[p] = pk::pack((int32_t)letter_m(ybase - p - 1), (int32_t)letter_m(ybase - p - RH - 1));
     }
+    // The planner's steady range allows a diagonal's LAST cell to be the last step of a steady block (every cell of
+    // the block is still valid); rules 1 / 2 capture that cell, which only the edge body does: give up that block.
+    const int sb1 = RULE == 0 ? wd.steady_b1 : wd.steady_b1 - 1;
     feed_issue(0);
     for (int b = 0; b < wd.nblocks; b++) {
       feed_commit(b);
       if (b + 1 < wd.nblocks) feed_issue(b + 1);
-      if (b >= wd.steady_b0 && b < wd.steady_b1) block16<false>(b);
+      if (b >= wd.steady_b0 && b < sb1) block16<false>(b);
       else block16<true>(b);
     }
     finish();

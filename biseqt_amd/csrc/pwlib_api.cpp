@@ -175,7 +175,7 @@ int batch_build(pw_batch* b) {
   // into the band is lowered by only 8192 (the sentinel), so no score -- in or out of the band -- may reach that
   // (regression: test_band_edge_never_leaks_long_pairs).
   // Rules 1 / 2 (B_OVERLAP / B_GLOBAL, WaveFill16<.., RULE>): scores go negative, the sentinel is -24000 and every
-  // real score must stay within +-15000.  Lower bound of any in-band cell: the straight run down its own diagonal
+  // real score must stay within [-23000, 30000].  Lower bound of any in-band cell: the straight run down its own diagonal
   // from the table edge (min(X,Y) substitutions) -- for B_GLOBAL after the gap run from (0, 0) to that diagonal.
   int pbk = 0, pnl = 0, pseg = 0, prule = -1;
   if (b->variant == pw::VAR_FAST_ANY_TRACK && track) prule = 0;
@@ -183,9 +183,13 @@ int batch_build(pw_batch* b) {
   else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
   bool pfits = false;
   if (prule == 0) pfits = (double)maxmin * std::max(mt, 0.0) <= 8000;
-  else if (prule > 0)
-    pfits = (double)maxmin * std::max(fabs(mt), fabs(mm)) + fabs(b->go) + fabs(b->ge) * (maxnd + 2) <= 15000 && b->go <= 0 &&
-            maxnd <= 64 * 20 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
+  else if (prule > 0) {
+    // real scores must stay above the values derived from the sentinel (<= -24000 + 100) and below int16's top
+    const double worst = std::max(0.0, -std::min(mt, mm));
+    const double lowest = (double)maxmin * worst + fabs(b->go) + fabs(b->ge) * (maxnd + 2);
+    const double highest = (double)maxmin * std::max(0.0, std::max(mt, mm));
+    pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && maxnd <= 64 * 20 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
+  }
   if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED)) && maxnd <= 2048 &&
       nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0) {

@@ -1,6 +1,8 @@
 """The kernel's lane program (biseqt_amd/csrc/pw_wave.h) and host planner (pw_plan.h), executed by the
 64-fiber CPU emulator of tests/emu, against the golden vectors and the oracle.  This is the CPU-side
 check of the device logic: same source, lockstep lanes, emulated DPP shifts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -157,3 +159,26 @@ def test_emu_packed16_overlap_and_global(oracle):
             assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
         n += 1
     assert n > 90
+
+
+def test_emu_packed16_overlap_last_cell_on_a_block_boundary(oracle):
+    """Regression (GPU fuzz, seed 51): a diagonal whose LAST cell is the last step of a block that the planner's steady
+    range still covers -- the overlap / global rules must run the edge body there to capture it."""
+    import json
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'packed_overlap_regression.json')))
+    o, m = np.array(rec['origin'], np.uint8), np.array(rec['mutant'], np.uint8)
+    sc = rec['scores']
+    kw = dict(L=4, mode=1, alntype=rec['alntype'], diag_range=tuple(rec['band']), match=float(sc[0]), mismatch=float(sc[1]),
+              go=float(sc[2]), ge=float(sc[3]))
+    a = oracle.solve(o, m, **kw)
+    for pk in (1, 2):
+        for bk in (4, 8):
+            b = emu.solve(o, m, bk=bk, packed16=pk, **kw)
+            for key in ('opt', 'score', 'transcript', 'origin_idx', 'mutant_idx'):
+                assert a.get(key) == b.get(key), (pk, bk, key)
+    # the same geometry family: every band end so that tl_min sweeps all residues modulo 16
+    for hi in range(80, 100):
+        kw['diag_range'] = (-84, hi)
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=4, packed16=2, **kw)
+        assert a['opt'] == b['opt'] and a['score'] == b['score'] and a['transcript'] == b['transcript'], hi

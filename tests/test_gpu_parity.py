@@ -571,6 +571,8 @@ def test_packed_overlap_and_global_kernels_at_their_bounds(oracle):
             (a, a.copy(), alntype, (-21, -1) if alntype == 2 else (-21, 0), dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)),
             (a, a.copy(), alntype, (1, 23) if alntype == 2 else (0, 23), dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)),
             (a, near, alntype, (min(0, len(a) - len(near)) - 37, max(0, len(a) - len(near)) + 41), dict(match_score=2, mismatch_score=-1, go_score=0, ge_score=-1)),
+            (a, b_, alntype, (-30, 33), dict(match_score=1, mismatch_score=-4, go_score=-9, ge_score=-3)),       # down to about -19700
+            (a, a.copy(), alntype, (-5, 4), dict(match_score=6, mismatch_score=-4, go_score=-9, ge_score=-3)),  # up to +29400
         ]
     for o, m, alntype, band, sc in cases:
         for n in (1, 300):                                   # latency layout / throughput layout (lane packing)
@@ -587,3 +589,30 @@ def test_packed_overlap_and_global_kernels_at_their_bounds(oracle):
                 if not r['would_panick'] and not r['tb_null']:
                     assert txs[k] == r['transcript']
                     assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def test_packed_overlap_global_sweep_of_band_ends(oracle):
+    """Regression family of tests/golden/packed_overlap_regression.json on the GPU: B_OVERLAP / B_GLOBAL with every band
+    end in a range, so that the step of the earliest-ending diagonal takes every residue modulo the 16-step block."""
+    import json
+    from biseqt_amd.batch import BatchAligner
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'packed_overlap_regression.json')))
+    o, m = np.array(rec['origin'], np.uint8), np.array(rec['mutant'], np.uint8)
+    for alntype in (2, 0):
+        bands = [(-84, hi) for hi in range(70, 104)] + [(lo, 60) for lo in range(-100, -70)]
+        if alntype == 0:
+            bands = [b for b in bands if b[0] <= len(o) - len(m) <= b[1]]
+        for n in (1, 300):
+            for chunk in range(0, len(bands), 8):
+                bs = bands[chunk:chunk + 8]
+                with BatchAligner([(o, m)] * (len(bs) * (n // 8 if n > 1 else 1)), alnmode=1, alntype=alntype, alphabet_len=4,
+                                  diag_range=bs * (n // 8 if n > 1 else 1), match_score=1, mismatch_score=-3, go_score=-5,
+                                  ge_score=-2) as bt:
+                    assert 'k_fill16' in bt.kernel_name
+                    res = bt.run()
+                    txs = bt.transcripts(res)
+                for k, band in enumerate(bs):
+                    r = oracle.solve(o, m, L=4, mode=1, alntype=alntype, diag_range=band, match=1, mismatch=-3, go=-5, ge=-2)
+                    assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score'], (alntype, band, n)
+                    if not r['would_panick'] and not r['tb_null']:
+                        assert txs[k] == r['transcript'], (alntype, band, n)
