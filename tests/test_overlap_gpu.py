@@ -133,3 +133,42 @@ def test_all_pairs_shards_partition_the_work():
     for name in recs.dtype.names:
         if name != 'pad_':
             assert (gr[order][name] == recs[name]).all(), name
+
+
+def test_all_pairs_random_read_sets():
+    """Random small read sets (repeats, duplicates, reads shorter than the word, two-letter reads) through the
+    one-index path -- the sparse one-wavefront kernel for pairs with few seeds and the histogram kernel for the
+    others -- against the pair-list path record for record."""
+    from biseqt_amd import synth
+    from biseqt_amd.overlap import raw_all_pairs, raw_bands
+    rng = synth.rng_for(314)
+    for trial in range(25):
+        R = int(rng.integers(2, 22))
+        k = int(rng.integers(3, 11))
+        g = synth.rand_seqs(rng, 1, 1500)[0]
+        reads = []
+        for _ in range(R):
+            kind = int(rng.integers(0, 6))
+            n = int(rng.integers(0, 500))
+            if kind == 0:
+                reads.append(synth.rand_seqs(rng, 1, n)[0])
+            elif kind == 1:
+                st = int(rng.integers(0, 1500 - n)) if n < 1500 else 0
+                reads.append(synth.mutate(rng, g[st:st + n], .05, .02, .3) if n else g[:0].copy())
+            elif kind == 2:
+                reads.append(np.resize(rng.integers(0, 4, int(rng.integers(1, 4))).astype(np.uint8), n))
+            elif kind == 3 and reads:
+                reads.append(reads[int(rng.integers(0, len(reads)))].copy())
+            elif kind == 4:
+                reads.append(rng.integers(0, 2, n).astype(np.uint8))
+            else:
+                reads.append(g[int(rng.integers(0, 700)):][:n].copy())
+        g_max, sens = float(rng.choice([.1, .2, .3])), float(rng.choice([.9, .99]))
+        pairs, recs, _ = raw_all_pairs(reads, k, 4, g_max, sens)
+        allp = [(a, b) for a in range(R) for b in range(a + 1, R)]
+        ref, _ = raw_bands(reads, allp, k, 4, g_max, sens)
+        keep = [q for q, r in enumerate(ref) if r['n_seeds'] > 0]
+        assert [tuple(p) for p in pairs.tolist()] == [allp[q] for q in keep], trial
+        for name in recs.dtype.names:
+            if name != 'pad_':
+                assert (recs[name] == ref[name][keep]).all(), (trial, name)
