@@ -163,7 +163,17 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int
 // kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.
 constexpr int kTileLanes = PW_TILE_LANES, kTileGhost = PW_TILE_GHOST, kTileCentral = kTileLanes - 2 * kTileGhost;
 struct DevPT {
-  PW_FN static int lane0() { return (int)blockIdx.x * kTileCentral - kTileGhost; }
+  // Workgroups are dealt to the 8 XCDs round-robin; neighbouring tiles exchange their state through memory between
+  // launches, so tile t = (b mod 8) * (grid / 8) + b / 8 keeps runs of consecutive tiles on one XCD (and its L2).
+  // (The grid is a multiple of 8; tiles beyond the band find no diagonal and do nothing.)
+  PW_FN static int tile() {
+#ifdef PW_TILE_NO_XCD_REMAP
+    return (int)blockIdx.x;
+#else
+    return (int)(blockIdx.x & 7u) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+#endif
+  }
+  PW_FN static int lane0() { return tile() * kTileCentral - kTileGhost; }
   PW_FN static int lane() { return lane0() + (int)threadIdx.x; }
   PW_FN static int nlanes() { return lane0() + kTileLanes; }      // global index one past this tile's last lane
   PW_FN static int nwaves() { return kTileLanes / 64; }
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(256) void k_tile_finish(const FillParams<T> a, cons
 
 template <typename T>
 hipError_t launch_tile_T(const FillParams<T>& a, int variant, int pair, int ntiles, hipStream_t st) {
-  const dim3 grid((unsigned)ntiles), block(kTileLanes);
+  const dim3 grid((unsigned)((ntiles + 7) / 8 * 8)), block(kTileLanes);      // a multiple of 8: see DevPT::tile()
   switch (variant) {
     case VAR_FAST_ANY_TRACK: hipLaunchKernelGGL((k_fill_tile<T, true, true, false>), grid, block, 0, st, a, pair); break;
     case VAR_FAST_TRACK: hipLaunchKernelGGL((k_fill_tile<T, false, true, false>), grid, block, 0, st, a, pair); break;
