@@ -6,11 +6,6 @@ the host; ``as_kmer_seq`` of a whole sequence is computed by the GPU encoder (ke
 ``KmerIndex`` / ``KmerCache`` of the reference are storage, not computation, and have no counterpart: the
 sorted (k-mer, position) arrays live in HBM inside :class:`biseqt_amd.seeds.SeedIndex`.
 """
-import ctypes as C
-
-import numpy as np
-
-from . import _pwlib as W
 from .sequence import Alphabet, Sequence
 
 DIGITS = '0123456789abcdefghijklmnopqrstuvwxyz'     # kmers.py:162: at most 36 letters

@@ -19,7 +19,7 @@ import numpy as np
 from . import _pwlib as W
 from .batch import DeviceBuffer
 from .kmers import check_limits, mask_bits
-from .sequence import Alphabet, Sequence
+from .sequence import Sequence
 
 
 class _Index(object):
