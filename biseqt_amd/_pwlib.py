@@ -122,7 +122,7 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_batch_trace_ms']
 # every symbol include/pw_seeds.h declares
 SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_seeds_is_self', 'pw_seeds_rows_device',
-                'pw_seeds_rows', 'pw_seeds_count', 'pw_seeds_kmers', 'pw_seeds_band_neighbours', 'pw_seeds_graph_build',
+                'pw_seeds_rows', 'pw_seeds_count', 'pw_seeds_kmers', 'pw_seeds_band_neighbours', 'pw_seeds_graph_build', 'pw_seeds_graph_num_points', 'pw_seeds_graph_points',
                 'pw_seeds_graph_counts', 'pw_seeds_graph_fetch', 'pw_seeds_graph_components', 'pw_seeds_build_ms',
                 'pw_seeds_algorithmic_bytes', 'pw_seeds_destroy', 'pw_seeds_last_error']
 
@@ -218,6 +218,9 @@ def load():
     lib.pw_seeds_band_neighbours.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
     lib.pw_seeds_graph_build.argtypes = [C.c_void_p, C.c_double, C.c_double]
     lib.pw_seeds_graph_build.restype = C.c_int64
+    lib.pw_seeds_graph_num_points.argtypes = [C.c_void_p]
+    lib.pw_seeds_graph_num_points.restype = C.c_int64
+    lib.pw_seeds_graph_points.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.pw_seeds_graph_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.pw_seeds_graph_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pw_seeds_graph_components.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -139,7 +139,6 @@ class WordBlot(SeedIndex):
     def _graph(self, d_radius, a_radius):
         """The neighbourhood graph of ``find_all_neighbors`` (``blot.py:343-374``), built on the GPU once per
         (d_radius, a_radius)."""
-        assert not self.self_comp, 'local similarity search between a sequence and itself is not supported'
         key = (d_radius, a_radius)
         if self._graph_key != key:
             self._idx.graph_build(1. * a_radius / d_radius, a_radius)
@@ -162,10 +161,12 @@ class WordBlot(SeedIndex):
     def score_seeds(self, K):
         """One dict per seed, in the class's seed order: ``seed`` (d, a), ``neighs`` (indices of the seeds in its
         neighbourhood), ``p`` estimated match probability of a segment centred there (``blot.py:376-408``)."""
-        rows = self.rows()
-        if not len(rows):
+        if not self.seed_count():
             return []
         p, _, _ = self._seed_ps(K)
+        rows = self._idx.graph_points()
+        if not len(rows):
+            return []
         off, adj = self._idx.graph_fetch()
         perm = self._presentation()
         if perm is None:
@@ -181,11 +182,14 @@ class WordBlot(SeedIndex):
         with ``p >= p_min`` are grown into connected groups (the reference's depth-first search finds the
         connected components of the neighbourhood graph; they are computed on the GPU), each group's bounding
         segment is clamped to the table, scored and yielded in the order of its first seed."""
-        rows = self.rows()
-        if not len(rows):
+        if not self.seed_count():
             assert not at_least_one, 'no seeds found while at_least_one=True'
             return
         p, d_radius, a_radius = self._seed_ps(K_min)
+        rows = self._idx.graph_points()              # the seeds as the class iterates them (mirrored for S == T)
+        if not len(rows):
+            assert not at_least_one, 'no seeds found while at_least_one=True'
+            return
         perm = self._presentation()
         if perm is None:
             rank = np.arange(len(rows))                  # position of every table row in the class's seed order

@@ -156,6 +156,22 @@ __global__ __launch_bounds__(256) void k_neigh(const double* __restrict__ x, con
   counts[o] = (int32_t)(lo - first - 1);
 }
 
+// Self comparison: the seeds a WordBlot iterates are SeedIndex.seeds(exclude_trivial=True) (seeds.py:186-197): every
+// non-trivial row (i < j, d < 0) followed by its mirror image, trivial rows (d = 0) dropped.
+__global__ __launch_bounds__(256) void k_self_flag(const int2* __restrict__ rows, int64_t n, uint64_t* __restrict__ flag) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o < n) flag[o] = rows[o].x != 0 ? 1ull : 0ull;
+}
+__global__ __launch_bounds__(256) void k_self_points(const int2* __restrict__ rows, int64_t n, const uint64_t* __restrict__ pos,
+                                                     int2* __restrict__ pts) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const int2 r = rows[o];
+  if (r.x == 0) return;
+  pts[2 * pos[o]] = r;
+  pts[2 * pos[o] + 1] = make_int2(-r.x, r.y);
+}
+
 // ---- K7: the neighbourhood graph of the seeds (blot.py:343-374) and its connected components (:452-468) ----------
 __global__ __launch_bounds__(256) void k_graph_keys(const int2* __restrict__ rows, int64_t n, int nT, uint64_t* __restrict__ keys,
                                                     uint32_t* __restrict__ vals) {
@@ -260,8 +276,8 @@ struct pw_seed_index {
   uint64_t kinv = 0;
   MaskSets ms;
   DevBuf dS, dT, keys_in, keys_s, keys_t, pos_in, pos_s, pos_t, lo, cnt, off, rows, tmp, scalar;
-  DevBuf g_keys, g_order, g_dstart, g_cnt, g_off, g_adj;     // neighbourhood graph (K7)
-  int64_t g_edges = -1;
+  DevBuf g_keys, g_order, g_dstart, g_cnt, g_off, g_adj, g_pts;     // neighbourhood graph (K7)
+  int64_t g_edges = -1, g_npts = -1;    // g_npts: points of the graph (= rows, or the mirrored non-trivial rows of a self comparison)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float ms_build = 0.f;
 };
@@ -328,7 +344,7 @@ int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   SD_CHECK(hipSetDevice(x->device));
   if (max_rows <= 0) max_rows = (1ll << 31) - 1;
-  x->nrows = -1; x->g_edges = -1;
+  x->nrows = -1; x->g_edges = -1; x->g_npts = -1;
   SD_CHECK(hipEventRecord(x->ev0, st));
   if (encode_sort(x, (const uint8_t*)x->dS.p, x->nS, x->nkS, x->keys_s, x->pos_s, st) != 0) return -1;
   if (!x->self && encode_sort(x, (const uint8_t*)x->dT.p, x->nT, x->nkT, x->keys_t, x->pos_t, st) != 0) return -1;
@@ -457,12 +473,34 @@ int pw_seeds_band_neighbours(const pw_seed_index* xc, const double* radius, int6
 
 int64_t pw_seeds_graph_build(pw_seed_index* x, double d_coeff, double radius) {
   if (!x || x->nrows < 0) { set_err("pw_seeds_graph_build before a successful pw_seeds_build"); return -1; }
-  if (x->self) { set_err("the neighbourhood graph is not defined for a self comparison"); return -1; }
   if (!(d_coeff > 0) || !(radius >= 0)) { set_err("d_coeff must be positive and radius non-negative"); return -1; }
-  x->g_edges = -1;
-  const int64_t n = x->nrows;
-  if (n == 0) { x->g_edges = 0; return 0; }
+  x->g_edges = -1; x->g_npts = -1;
   SD_CHECK(hipSetDevice(x->device));
+  const int2* pts = (const int2*)x->rows.p;
+  int64_t n = x->nrows;
+  if (x->self && n > 0) {
+    // the point list of a self comparison: non-trivial rows and their mirror images, in table order
+    DevBuf flag, pos;
+    if (flag.ensure((size_t)n * 8) != 0 || pos.ensure((size_t)n * 8) != 0) { flag.release(); pos.release(); return -1; }
+    const dim3 g((unsigned)((n + 255) / 256)), bl(256);
+    hipLaunchKernelGGL(k_self_flag, g, bl, 0, nullptr, (const int2*)x->rows.p, n, (uint64_t*)flag.p);
+    size_t tbs = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tbs, (const uint64_t*)flag.p, (uint64_t*)pos.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), (hipStream_t) nullptr);
+    if (e == hipSuccess && x->tmp.ensure(tbs) != 0) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = rocprim::exclusive_scan(x->tmp.p, tbs, (const uint64_t*)flag.p, (uint64_t*)pos.p, (uint64_t)0, (size_t)n, rocprim::plus<uint64_t>(), (hipStream_t) nullptr);
+    uint64_t lp = 0, lf = 0;
+    if (e == hipSuccess) e = hipMemcpy(&lp, (uint64_t*)pos.p + (n - 1), 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&lf, (uint64_t*)flag.p + (n - 1), 8, hipMemcpyDeviceToHost);
+    const int64_t np = (int64_t)(2 * (lp + lf));
+    if (e == hipSuccess && x->g_pts.ensure((size_t)std::max<int64_t>(np, 1) * 8) != 0) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) hipLaunchKernelGGL(k_self_points, g, bl, 0, nullptr, (const int2*)x->rows.p, n, (const uint64_t*)pos.p, (int2*)x->g_pts.p);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    flag.release(); pos.release();
+    if (e != hipSuccess) { set_err("building the point list of the self comparison failed"); return -1; }
+    pts = (const int2*)x->g_pts.p; n = np;
+  }
+  x->g_npts = n;
+  if (n == 0) { x->g_edges = 0; return 0; }
   const int64_t nd = x->nS + x->nT + 1;
   const double wd = floor(radius / d_coeff) + 2;
   const int win = wd > (double)nd ? (int)nd : (int)wd;
@@ -473,7 +511,7 @@ int64_t pw_seeds_graph_build(pw_seed_index* x, double d_coeff, double radius) {
     if (x->g_keys.ensure((size_t)n * 8) != 0 || x->g_order.ensure((size_t)n * 4) != 0 || x->g_dstart.ensure((size_t)(nd + 1) * 4) != 0 ||
         x->g_cnt.ensure((size_t)n * 4) != 0 || x->g_off.ensure((size_t)(n + 1) * 8) != 0) break;
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    hipLaunchKernelGGL(k_graph_keys, grid, blk, 0, nullptr, (const int2*)x->rows.p, n, (int)x->nT, (uint64_t*)kin.p, (uint32_t*)vin.p);
+    hipLaunchKernelGGL(k_graph_keys, grid, blk, 0, nullptr, pts, n, (int)x->nT, (uint64_t*)kin.p, (uint32_t*)vin.p);
     int dbits = 1; while (((uint64_t)nd >> dbits) != 0) dbits++;
     size_t tb = 0;
     if (rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)kin.p, (uint64_t*)x->g_keys.p, (const uint32_t*)vin.p, (uint32_t*)x->g_order.p,
@@ -509,26 +547,36 @@ int64_t pw_seeds_graph_build(pw_seed_index* x, double d_coeff, double radius) {
   return rc;
 }
 
+int64_t pw_seeds_graph_num_points(const pw_seed_index* x) { return (x && x->g_edges >= 0) ? x->g_npts : -1; }
+
+int pw_seeds_graph_points(const pw_seed_index* x, int32_t* da, int64_t cap) {
+  if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_points before a successful pw_seeds_graph_build"); return -1; }
+  if (cap < x->g_npts) { set_err("pw_seeds_graph_points: capacity too small"); return -1; }
+  SD_CHECK(hipSetDevice(x->device));
+  if (x->g_npts) SD_CHECK(hipMemcpy(da, x->self ? x->g_pts.p : x->rows.p, (size_t)x->g_npts * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int pw_seeds_graph_counts(const pw_seed_index* x, int32_t* counts, int64_t cap) {
   if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_counts before a successful pw_seeds_graph_build"); return -1; }
-  if (cap < x->nrows) { set_err("pw_seeds_graph_counts: capacity too small"); return -1; }
+  if (cap < x->g_npts) { set_err("pw_seeds_graph_counts: capacity too small"); return -1; }
   SD_CHECK(hipSetDevice(x->device));
-  if (x->nrows) SD_CHECK(hipMemcpy(counts, x->g_cnt.p, (size_t)x->nrows * 4, hipMemcpyDeviceToHost));
+  if (x->g_npts) SD_CHECK(hipMemcpy(counts, x->g_cnt.p, (size_t)x->g_npts * 4, hipMemcpyDeviceToHost));
   return 0;
 }
 
 int pw_seeds_graph_fetch(const pw_seed_index* x, int64_t* offsets, int32_t* neighbours) {
   if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_fetch before a successful pw_seeds_graph_build"); return -1; }
   SD_CHECK(hipSetDevice(x->device));
-  if (x->nrows == 0) { offsets[0] = 0; return 0; }
-  SD_CHECK(hipMemcpy(offsets, x->g_off.p, (size_t)(x->nrows + 1) * 8, hipMemcpyDeviceToHost));
+  if (x->g_npts == 0) { offsets[0] = 0; return 0; }
+  SD_CHECK(hipMemcpy(offsets, x->g_off.p, (size_t)(x->g_npts + 1) * 8, hipMemcpyDeviceToHost));
   if (x->g_edges) SD_CHECK(hipMemcpy(neighbours, x->g_adj.p, (size_t)x->g_edges * 4, hipMemcpyDeviceToHost));
   return 0;
 }
 
 int pw_seeds_graph_components(const pw_seed_index* x, const uint8_t* avail, int32_t* labels) {
   if (!x || x->g_edges < 0) { set_err("pw_seeds_graph_components before a successful pw_seeds_graph_build"); return -1; }
-  const int64_t n = x->nrows;
+  const int64_t n = x->g_npts;
   if (n == 0) return 0;
   SD_CHECK(hipSetDevice(x->device));
   DevBuf av, par, flag;
@@ -560,7 +608,7 @@ void pw_seeds_destroy(pw_seed_index* x) {
   if (!x) return;
   (void)hipSetDevice(x->device);
   DevBuf* bufs[] = {&x->dS, &x->dT, &x->keys_in, &x->keys_s, &x->keys_t, &x->pos_in, &x->pos_s, &x->pos_t, &x->lo, &x->cnt,
-                    &x->off, &x->rows, &x->tmp, &x->scalar, &x->g_keys, &x->g_order, &x->g_dstart, &x->g_cnt, &x->g_off, &x->g_adj};
+                    &x->off, &x->rows, &x->tmp, &x->scalar, &x->g_keys, &x->g_order, &x->g_dstart, &x->g_cnt, &x->g_off, &x->g_adj, &x->g_pts};
   for (DevBuf* b : bufs) b->release();
   if (x->ev0) (void)hipEventDestroy(x->ev0);
   if (x->ev1) (void)hipEventDestroy(x->ev1);

@@ -85,8 +85,17 @@ class _Index(object):
         self._edges = e
         return e
 
+    def graph_points(self):
+        """(n, 2) int32 array of the graph's points (d, a): the rows, or for a self comparison the non-trivial rows
+        each followed by its mirror image."""
+        n = self.lib.pw_seeds_graph_num_points(self.handle)
+        out = np.zeros((max(n, 1), 2), np.int32)
+        if self.lib.pw_seeds_graph_points(self.handle, out.ctypes.data, n) != 0:
+            raise RuntimeError('pw_seeds_graph_points failed: ' + self.error())
+        return out[:n]
+
     def graph_counts(self):
-        n = self.lib.pw_seeds_num_rows(self.handle)
+        n = self.lib.pw_seeds_graph_num_points(self.handle)
         out = np.zeros(max(n, 1), np.int32)
         if self.lib.pw_seeds_graph_counts(self.handle, out.ctypes.data, n) != 0:
             raise RuntimeError('pw_seeds_graph_counts failed: ' + self.error())
@@ -94,7 +103,7 @@ class _Index(object):
 
     def graph_fetch(self):
         """CSR adjacency: (offsets[n + 1], neighbours[edges])."""
-        n = self.lib.pw_seeds_num_rows(self.handle)
+        n = self.lib.pw_seeds_graph_num_points(self.handle)
         off = np.zeros(n + 1, np.int64)
         adj = np.zeros(max(self._edges, 1), np.int32)
         if self.lib.pw_seeds_graph_fetch(self.handle, off.ctypes.data, adj.ctypes.data) != 0:
@@ -102,7 +111,7 @@ class _Index(object):
         return off, adj[:self._edges]
 
     def graph_components(self, avail):
-        n = self.lib.pw_seeds_num_rows(self.handle)
+        n = self.lib.pw_seeds_graph_num_points(self.handle)
         av = np.ascontiguousarray(avail, np.uint8)
         assert av.size == n
         out = np.full(max(n, 1), -1, np.int32)

@@ -72,10 +72,13 @@ int pw_seeds_band_neighbours(const pw_seed_index* idx, const double* radius, int
  *     max(|d * d_coeff - d' * d_coeff|, |a - a'|) <= radius
  * -- cKDTree.query_ball_tree(radius, p = inf) over the points (d * d_coeff, a), each row's own entry removed --
  * and keeps the adjacency in HBM as CSR.  Returns the number of directed edges (every pair counts twice), or -1.
- * Not defined for self comparisons. */
+ * The POINTS of the graph are the rows -- for a self comparison what SeedIndex.seeds(exclude_trivial=True) yields
+ * (seeds.py:186-197): every non-trivial row followed by its mirror image (-d, a), trivial rows dropped. */
 int64_t pw_seeds_graph_build(pw_seed_index* idx, double d_coeff, double radius);
-int pw_seeds_graph_counts(const pw_seed_index* idx, int32_t* counts, int64_t cap);          /* neighbours per row */
-/* offsets: num_rows + 1 entries; neighbours: pw_seeds_graph_build's return value entries (row indices, the order
+int64_t pw_seeds_graph_num_points(const pw_seed_index* idx);
+int pw_seeds_graph_points(const pw_seed_index* idx, int32_t* da, int64_t cap);      /* (d, a) of every point, in order */
+int pw_seeds_graph_counts(const pw_seed_index* idx, int32_t* counts, int64_t cap);          /* neighbours per point */
+/* offsets: num_points + 1 entries; neighbours: pw_seeds_graph_build's return value entries (row indices, the order
  * inside a row's list is unspecified -- it is in the reference as well). */
 int pw_seeds_graph_fetch(const pw_seed_index* idx, int64_t* offsets, int32_t* neighbours);
 /* Connected components of the graph restricted to the rows with avail[row] != 0 (the depth-first growth of

@@ -177,3 +177,32 @@ def test_in_memory_ref_variants(wordlen):
         if rec is not None:
             assert rec['d_band'] == ref['d_band'] and rec['p'] == ref['p'] and rec['score'] == ref['score']
     loc.close(); ovl.close()
+
+
+def test_self_similarity_vs_oracle():
+    """WordBlot(S, S): the reference turns equal contents into a self comparison (seeds.py:33) -- the seeds it iterates
+    are the non-trivial matches, each followed by its mirror image, while seed_count still counts table rows.  A
+    sequence with internal repeats against itself: score_seeds and similar_segments equal to the oracle's."""
+    from biseqt_amd import synth
+    from biseqt_amd.blot import WordBlot
+    from biseqt_amd.sequence import Alphabet
+    from oracle import blot_oracle as BO
+    A = Alphabet('ACGT')
+    rng = synth.rng_for(808)
+    unit = synth.rand_seqs(rng, 1, 300)[0]
+    s = np.concatenate([synth.rand_seqs(rng, 1, 400)[0], unit, synth.rand_seqs(rng, 1, 350)[0],
+                        synth.mutate(rng, unit, .04, .02, .3), synth.rand_seqs(rng, 1, 200)[0]])
+    for wordlen, K in ((6, 120), (8, 200)):
+        wb = WordBlot(_mk(A, s), _mk(A, s), g_max=.2, sensitivity=.99, alphabet=A, wordlen=wordlen)
+        assert wb.self_comp
+        got = wb.score_seeds(K)
+        exp = BO.score_seeds_local(s.tolist(), s.tolist(), wordlen, 4, .2, .99, K)
+        assert [(g['seed'], g['p'], sorted(g['neighs'])) for g in got] == [(e['seed'], e['p'], sorted(e['neighs'])) for e in exp]
+        for p_min in (.6, .85):
+            gs = list(wb.similar_segments(K, p_min))
+            es = BO.similar_segments(s.tolist(), s.tolist(), wordlen, 4, .2, .99, K, p_min)
+            assert [g['segment'] for g in gs] == [e['segment'] for e in es] and len(gs) >= 2
+            for g, e in zip(gs, es):
+                assert abs(g['p'] - e['p']) <= 1e-12 * max(abs(e['p']), 1e-300)
+                assert np.allclose(g['scores'], e['scores'], rtol=1e-9, atol=0)
+        wb.close()
