@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <string>
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "../../include/pw_batch.h"
@@ -29,6 +30,55 @@ static_assert(sizeof(pw::PairDesc) == 96, "PairDesc layout");
 
 namespace {
 int env_int(const char* name, int dflt);
+
+// A small cache of the big device buffers (tie-mask planes, transcript slots): freeing and re-allocating tens of GB per
+// batch stalls in the driver for seconds at a time (measured in the config-4 alignment stage).  Buffers of at least
+// 1 MB are kept on pw_batch_destroy, up to PWLIB_POOL_GB in total (default 64; 0 disables), and handed to the next
+// batch that fits within a factor of two.  pw_pool_trim() releases everything.
+struct PoolEntry { void* p; size_t bytes; int device; };
+std::mutex g_pool_mutex;
+std::vector<PoolEntry> g_pool;
+size_t g_pool_held = 0;
+
+void* pool_take(int device, size_t bytes, size_t* got) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  int best = -1;
+  for (int i = 0; i < (int)g_pool.size(); i++)
+    if (g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + (1u << 20) &&
+        (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+  if (best < 0) return nullptr;
+  void* p = g_pool[best].p; *got = g_pool[best].bytes;
+  g_pool_held -= g_pool[best].bytes;
+  g_pool.erase(g_pool.begin() + best);
+  return p;
+}
+void pool_give(int device, void* p, size_t bytes) {
+  if (!p) return;
+  const size_t cap = (size_t)env_int("PWLIB_POOL_GB", 64) << 30;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (bytes >= (1u << 20) && g_pool_held + bytes <= cap && g_pool.size() < 32) {
+      g_pool.push_back(PoolEntry{p, bytes, device});
+      g_pool_held += bytes;
+      return;
+    }
+  }
+  (void)hipFree(p);
+}
+hipError_t pool_alloc(int device, void** p, size_t bytes, size_t* got) {
+  *p = pool_take(device, bytes, got);
+  if (*p) return hipSuccess;
+  *got = bytes;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {           // out of memory with buffers parked in the pool: release them and retry once
+    (void)hipGetLastError();
+    std::vector<PoolEntry> drop;
+    { std::lock_guard<std::mutex> lk(g_pool_mutex); drop.swap(g_pool); g_pool_held = 0; }
+    for (auto& d : drop) (void)hipFree(d.p);
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
 
 thread_local std::string g_err;
 
@@ -72,10 +122,10 @@ struct pw_batch {
   // device
   uint8_t* d_arena = nullptr; uint64_t arena_bytes = 0;
   pw::PairDesc* d_pairs = nullptr;
-  uint32_t* d_masks = nullptr; uint64_t mask_words = 0;
+  uint32_t* d_masks = nullptr; uint64_t mask_words = 0; size_t masks_alloc = 0, arena_alloc = 0, pairs_alloc = 0, results_alloc = 0;
   void* d_hdump = nullptr; uint64_t h_elems = 0;
   pw::Result* d_results = nullptr;
-  uint8_t* d_tx = nullptr; uint64_t tx_bytes = 0;
+  uint8_t* d_tx = nullptr; uint64_t tx_bytes = 0; size_t tx_alloc = 0;
   void* d_subst = nullptr;
   int32_t* d_ends = nullptr;
   hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr, ev_tr0 = nullptr, ev_tr1 = nullptr;
@@ -88,12 +138,12 @@ int batch_free_device(pw_batch* b) {
   if (!b) return 0;
   (void)hipSetDevice(b->device);
   for (auto& c : b->classes) if (c.d_order) (void)hipFree(c.d_order);
-  if (b->d_arena) (void)hipFree(b->d_arena);
-  if (b->d_pairs) (void)hipFree(b->d_pairs);
-  if (b->d_masks) (void)hipFree(b->d_masks);
+  pool_give(b->device, b->d_arena, b->arena_alloc);
+  pool_give(b->device, b->d_pairs, b->pairs_alloc);
+  pool_give(b->device, b->d_masks, b->masks_alloc);
   if (b->d_hdump) (void)hipFree(b->d_hdump);
-  if (b->d_results) (void)hipFree(b->d_results);
-  if (b->d_tx) (void)hipFree(b->d_tx);
+  pool_give(b->device, b->d_results, b->results_alloc);
+  pool_give(b->device, b->d_tx, b->tx_alloc);
   if (b->d_subst) (void)hipFree(b->d_subst);
   if (b->d_ends) (void)hipFree(b->d_ends);
   if (b->d_waves) (void)hipFree(b->d_waves);
@@ -109,6 +159,7 @@ int batch_free_device(pw_batch* b) {
 bool is_integral(double v) { return v == floor(v) && fabs(v) < 1e9; }
 
 int batch_build(pw_batch* b) {
+  const double t_build0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   // ---- scoring analysis ----
   const int L = b->L;
   bool integral = is_integral(b->go) && is_integral(b->ge);
@@ -286,13 +337,16 @@ int batch_build(pw_batch* b) {
     }
   }
   // ---- device buffers ----
+  const bool tim = env_int("PWLIB_TIMING", 0) != 0;
+  auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_plan = tnow();
   HIP_TRY(hipSetDevice(b->device));
   b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
-  HIP_TRY(hipMalloc((void**)&b->d_arena, b->arena_bytes + 16));   // kernels read whole dwords: slack past the last frame
-  HIP_TRY(hipMalloc((void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1)));
-  HIP_TRY(hipMalloc((void**)&b->d_masks, 4 * mask_words + 64));   // slack: the walker reads whole 16-byte groups
-  HIP_TRY(hipMalloc((void**)&b->d_results, sizeof(pw::Result) * std::max<int32_t>(b->n, 1)));
-  HIP_TRY(hipMalloc((void**)&b->d_tx, std::max<uint64_t>(tx_bytes, 16)));
+  HIP_TRY(pool_alloc(b->device, (void**)&b->d_arena, b->arena_bytes + 16, &b->arena_alloc));   // kernels read whole dwords: slack past the last frame
+  HIP_TRY(pool_alloc(b->device, (void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1), &b->pairs_alloc));
+  HIP_TRY(pool_alloc(b->device, (void**)&b->d_masks, 4 * mask_words + 64, &b->masks_alloc));   // slack: the walker reads whole 16-byte groups
+  HIP_TRY(pool_alloc(b->device, (void**)&b->d_results, sizeof(pw::Result) * std::max<int32_t>(b->n, 1), &b->results_alloc));
+  HIP_TRY(pool_alloc(b->device, (void**)&b->d_tx, std::max<uint64_t>(tx_bytes, 16), &b->tx_alloc));
   const size_t esz = b->use_f64 ? 8 : 4;
   if (h_elems) HIP_TRY(hipMalloc(&b->d_hdump, esz * h_elems));
   HIP_TRY(hipMalloc(&b->d_subst, esz * (size_t)L * L));
@@ -325,6 +379,7 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipEventCreate(&b->ev_fill0)); HIP_TRY(hipEventCreate(&b->ev_fill1));
     HIP_TRY(hipEventCreate(&b->ev_tr0)); HIP_TRY(hipEventCreate(&b->ev_tr1));
   }
+  if (tim && b->n > 1000) fprintf(stderr, "pwlib timing: batch of %d pairs: planning %.1f ms, device buffers + descriptors %.1f ms\n", b->n, t_plan - t_build0, tnow() - t_plan);
   return 0;
 }
 
@@ -380,6 +435,12 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
 extern "C" {
 
 const char* pw_last_error(void) { return g_err.c_str(); }
+
+void pw_pool_trim(void) {
+  std::vector<PoolEntry> drop;
+  { std::lock_guard<std::mutex> lk(g_pool_mutex); drop.swap(g_pool); g_pool_held = 0; }
+  for (auto& d : drop) { (void)hipSetDevice(d.device); (void)hipFree(d.p); }
+}
 
 int pw_device_count(void) {
   int n = 0;

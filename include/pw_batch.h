@@ -70,6 +70,10 @@ int pw_device_count(void);
 /* Plans the batch (band clamp / feasibility per pair exactly as dptable_init), picks the kernel variants,
  * allocates every device buffer and uploads the descriptors.  The arena is `arena_bytes` long; its
  * contents are supplied later (pw_batch_upload_arena or pw_batch_arena_device).  NULL on error. */
+/* The library keeps the big device buffers of destroyed batches (>= 1 MB each, PWLIB_POOL_GB in total, default 64,
+ * 0 disables) for the next batch; pw_pool_trim releases them. */
+void pw_pool_trim(void);
+
 pw_batch* pw_batch_create(int device, const pw_scoring* scoring, int32_t n_pairs, const pw_pair* pairs,
                           uint64_t arena_bytes, uint32_t flags);
 void pw_batch_destroy(pw_batch* b);
