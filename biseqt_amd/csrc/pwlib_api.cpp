@@ -66,6 +66,12 @@ void pool_give(int device, void* p, size_t bytes) {
   (void)hipFree(p);
 }
 hipError_t pool_alloc(int device, void** p, size_t bytes, size_t* got) {
+  // size classes, 8 per octave: consecutive batches of similar size then reuse each other's buffers
+  if (bytes >= (1u << 20)) {
+    int lg = 0; while ((bytes >> (lg + 1)) != 0) lg++;
+    const size_t step = (size_t)1 << (lg - 3);
+    bytes = (bytes + step - 1) / step * step;
+  }
   *p = pool_take(device, bytes, got);
   if (*p) return hipSuccess;
   *got = bytes;
