@@ -616,3 +616,36 @@ def test_packed_overlap_global_sweep_of_band_ends(oracle):
                     assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score'], (alntype, band, n)
                     if not r['would_panick'] and not r['tb_null']:
                         assert txs[k] == r['transcript'], (alntype, band, n)
+
+
+def test_drop_in_calls_from_several_threads(oracle):
+    """Distinct dptables are independent (the reference has no shared mutable state; cffi / ctypes release the
+    GIL around the calls): four threads run init / solve / traceback / free cycles concurrently."""
+    import threading
+    from biseqt_amd import synth, _pwlib as W
+    from oracle import ref_driver as R
+    lib = R.load(W.PWLIB_SO)
+    origins, mutants = synth.pair_batch(21, 8, 600)
+    probs, want = [], []
+    for k in range(8):
+        kw = dict(mode=1, alntype=k % 3, diag_range=(-60, 70), L=4, match=1., mismatch=-3., go=-5., ge=-2.)
+        probs.append(lambda k=k, kw=kw: R.Problem(origins[k].tolist(), mutants[k].tolist(), **kw))
+        want.append(oracle.solve(origins[k], mutants[k], **kw))
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(40):
+                k = (tid * 3 + it) % 8
+                out = R.run(lib, probs[k]())
+                w = want[k]
+                assert out['opt'] == w['opt'] and out['score'] == w['score'] and out['transcript'] == w['transcript'], (tid, it, k)
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
