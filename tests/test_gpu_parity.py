@@ -649,3 +649,33 @@ def test_drop_in_calls_from_several_threads(oracle):
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+def test_buffer_pool_reuse_and_trim():
+    """Device buffers of a destroyed batch are handed to the next batch of similar size (no growth over repeated
+    create / destroy cycles) and pw_pool_trim gives them back."""
+    import torch
+    from biseqt_amd import synth, _pwlib as W
+    from biseqt_amd.batch import BatchAligner
+    lib = W.load()
+    origins, mutants = synth.pair_batch(5, 600, 1500)
+    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-150, 150), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
+
+    def used():
+        free, total = torch.cuda.mem_get_info()
+        return (total - free) / 2.0 ** 20
+
+    with BatchAligner(list(zip(origins, mutants)), **kw) as b:      # warm-up: code objects, runtime scratch
+        b.run()
+    lib.pw_pool_trim()
+    base = used()
+    marks = []
+    for it in range(6):
+        with BatchAligner(list(zip(origins, mutants)), **kw) as b:
+            res = b.run()
+            assert (res['opt_i'] >= 0).all()
+        marks.append(used())
+    assert max(marks[1:]) - marks[1] < 32, marks          # steady after the first cycle
+    assert marks[1] - base > 50                           # ... because the buffers are parked in the pool
+    lib.pw_pool_trim()
+    assert used() - base < 32
