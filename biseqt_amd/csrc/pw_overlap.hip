@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void k_enc_batch(const uint8_t* __restrict__ a
 __global__ __launch_bounds__(256) void k_join_hist(const uint64_t* __restrict__ ks, const uint32_t* __restrict__ ps, int64_t ns,
                                                    const uint64_t* __restrict__ kt, const uint32_t* __restrict__ pt, int64_t nt,
                                                    const DPair* __restrict__ pairs, int kbits, uint32_t* __restrict__ hist,
-                                                   unsigned long long* __restrict__ nrows, uint32_t* __restrict__ first_e) {
+                                                   unsigned long long* __restrict__ nrows, uint32_t* __restrict__ first_e,
+                                                   int32_t* __restrict__ dlist /* [npairs][64]: the diagonals of a pair's first 64 seeds */) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= ns) return;
   const uint64_t key = ks[e];
@@ -78,8 +79,13 @@ __global__ __launch_bounds__(256) void k_join_hist(const uint64_t* __restrict__ 
   const DPair pr = pairs[p];
   const int i = (int)ps[e];
   uint32_t* __restrict__ h = hist + pr.hbase + pr.t_len;      // h[d], d = -t_len .. s_len
-  for (int64_t t = lo; t < hi; t++) atomicAdd(&h[i - (int)pt[t]], 1u);
-  atomicAdd(&nrows[p], (unsigned long long)(hi - lo));
+  const unsigned long long slot0 = atomicAdd(&nrows[p], (unsigned long long)(hi - lo));
+  for (int64_t t = lo; t < hi; t++) {
+    const int d = i - (int)pt[t];
+    atomicAdd(&h[d], 1u);
+    const unsigned long long slot = slot0 + (unsigned long long)(t - lo);
+    if (slot < 64ull) dlist[p * 64 + (int64_t)slot] = d;      // pairs with <= 64 seeds are scored from this list (K8d)
+  }
   atomicMin(&first_e[p], (uint32_t)e);                        // (fewer than 2^32 k-mers per chunk, checked by the host)
 }
 
@@ -281,9 +287,12 @@ __global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict_
 
 // K8d: a pair with at most 64 seeds is scored by ONE wavefront straight from its seed list (lane l = seed l, in table
 // order): same L, r, window, n, w as k_band_select's eval(), the neighbour count by a shuffle loop over the lanes.
+// Seeds of pair u: dval[soff[u] + l] in table order (all-pairs path, soff != nullptr) or dval[64 u + l] in arbitrary order
+// with the first row's diagonal given in d_first (pair-list path).
 __global__ __launch_bounds__(256) void k_band_small(const DPair* __restrict__ pairs, const uint64_t* __restrict__ soff,
                                                     const unsigned long long* __restrict__ cnt, const int32_t* __restrict__ dval,
-                                                    int64_t np, BandConst c, pw_overlap_band* __restrict__ out) {
+                                                    const int32_t* __restrict__ d_first, int64_t np, BandConst c,
+                                                    pw_overlap_band* __restrict__ out) {
   const int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int l = (int)(threadIdx.x & 63u);
   if (u >= np) return;
@@ -292,7 +301,8 @@ __global__ __launch_bounds__(256) void k_band_small(const DPair* __restrict__ pa
   const DPair pr = pairs[u];
   const int ls = pr.s_len, lt = pr.t_len;
   const bool valid = l < ns;
-  const int d = valid ? dval[soff[u] + (uint64_t)l] : 0x7fffffff;
+  const int d = valid ? dval[(soff ? soff[u] : (uint64_t)u * 64ull) + (uint64_t)l] : 0x7fffffff;
+  if (ns == 0) return;
   int L = 1, r = 1, first = 0, last = 0;
   if (valid) {
     L = ov_len(d, ls, lt, c.q); r = ov_rad(L, c.C);
@@ -324,7 +334,9 @@ __global__ __launch_bounds__(256) void k_band_small(const DPair* __restrict__ pa
   const unsigned long long win_mask = __ballot(rep && d == bd);
   const int wl = __ffsll((long long)win_mask) - 1;
   const int rb = __shfl(r, wl, 64), Lb = __shfl(L, wl, 64), nb = __shfl(n, wl, 64);
-  const int r0 = __shfl(r, 0, 64), L0 = __shfl(L, 0, 64), n0 = __shfl(n, 0, 64), d0 = __shfl(d, 0, 64);
+  const int d0 = d_first ? d_first[u] : __shfl(d, 0, 64);
+  const int fl = __ffsll((long long)__ballot(valid && d == d0)) - 1;      // a seed on the first row's diagonal
+  const int r0 = __shfl(r, fl, 64), L0 = __shfl(L, fl, 64), n0 = __shfl(n, fl, 64);
   const unsigned long long band_b = __ballot(valid && d >= bd - rb && d <= bd + rb);
   const unsigned long long band_f = __ballot(valid && d >= d0 - r0 && d <= d0 + r0);
   if (l == 0) {
@@ -362,11 +374,12 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
     ct += pairs[p].t_len >= k ? (uint64_t)(pairs[p].t_len - k + 1) : 0;
   }
   ss[(size_t)n] = cs; ts[(size_t)n] = ct;
-  Buf dp, dss, dts, kin, pin, ksb, psb, ktb, ptb, hist, rows, first, dout, tmp;
+  Buf dp, dss, dts, kin, pin, ksb, psb, ktb, ptb, hist, rows, first, dout, tmp, dlist;
   if (dp.alloc(sizeof(DPair) * (size_t)n) || dss.alloc(8 * ((size_t)n + 1)) || dts.alloc(8 * ((size_t)n + 1)) ||
       kin.alloc(8 * (size_t)std::max(cs, ct)) || pin.alloc(4 * (size_t)std::max(cs, ct)) || ksb.alloc(8 * (size_t)cs) ||
       psb.alloc(4 * (size_t)cs) || ktb.alloc(8 * (size_t)ct) || ptb.alloc(4 * (size_t)ct) || hist.alloc(4 * (size_t)hb) ||
-      rows.alloc(8 * (size_t)n) || first.alloc(4 * (size_t)n) || dout.alloc(sizeof(pw_overlap_band) * (size_t)n)) return -1;
+      rows.alloc(8 * (size_t)n) || first.alloc(4 * (size_t)n) || dout.alloc(sizeof(pw_overlap_band) * (size_t)n) ||
+      dlist.alloc(256 * (size_t)n)) return -1;
   OV_CHECK(hipMemcpy(dp.p, hp.data(), sizeof(DPair) * (size_t)n, hipMemcpyHostToDevice));
   OV_CHECK(hipMemcpy(dss.p, ss.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice));
   OV_CHECK(hipMemcpy(dts.p, ts.data(), 8 * ((size_t)n + 1), hipMemcpyHostToDevice));
@@ -391,14 +404,17 @@ int run_chunk(const uint8_t* d_arena, const pw_read_pair* pairs, int64_t n, int 
   if (cs && ct)
     hipLaunchKernelGGL(k_join_hist, dim3((unsigned)((cs + 255) / 256)), dim3(256), 0, nullptr, (const uint64_t*)ksb.p,
                        (const uint32_t*)psb.p, (int64_t)cs, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
-                       (const DPair*)dp.p, kbits, (uint32_t*)hist.p, (unsigned long long*)rows.p, (uint32_t*)first.p);
+                       (const DPair*)dp.p, kbits, (uint32_t*)hist.p, (unsigned long long*)rows.p, (uint32_t*)first.p, (int32_t*)dlist.p);
   Buf dfirst;
   if (dfirst.alloc(4 * (size_t)n)) return -1;
   hipLaunchKernelGGL(k_first_d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const uint32_t*)first.p, n,
                      (const uint64_t*)ksb.p, (const uint32_t*)psb.p, (const uint64_t*)ktb.p, (const uint32_t*)ptb.p, (int64_t)ct,
                      (int32_t*)dfirst.p);
+  hipLaunchKernelGGL(k_band_small, dim3((unsigned)(((uint64_t)n * 64 + 255) / 256)), dim3(256), 0, nullptr, (const DPair*)dp.p,
+                     (const uint64_t*)nullptr, (const unsigned long long*)rows.p, (const int32_t*)dlist.p, (const int32_t*)dfirst.p, n, bc,
+                     (pw_overlap_band*)dout.p);
   hipLaunchKernelGGL(k_band_select, dim3((unsigned)n), dim3(256), 0, nullptr, (const DPair*)dp.p, (uint32_t*)hist.p,
-                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, (uint64_t)0, 0, bc, (pw_overlap_band*)dout.p);
+                     (const unsigned long long*)rows.p, (const int32_t*)dfirst.p, (uint64_t)0, kSmallPair, bc, (pw_overlap_band*)dout.p);
   OV_CHECK(hipEventRecord(ev1, nullptr));
   OV_CHECK(hipMemcpy(out, dout.p, sizeof(pw_overlap_band) * (size_t)n, hipMemcpyDeviceToHost));
   OV_CHECK(hipGetLastError());
@@ -499,7 +515,7 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
                      (const uint64_t*)droff.p, (const int32_t*)drlen.p, (const uint64_t*)hbase.p, (DPair*)dpairs.p, (int32_t*)dfirst.p,
                      (int32_t*)dpa.p, (int32_t*)dpb.p);
   hipLaunchKernelGGL(k_band_small, dim3((unsigned)((NP * 64 + 255) / 256)), blk, 0, nullptr, (const DPair*)dpairs.p, (const uint64_t*)soff.p,
-                     (const unsigned long long*)uc.p, (const int32_t*)dv.p, (int64_t)NP, bc, (pw_overlap_band*)dout.p);
+                     (const unsigned long long*)uc.p, (const int32_t*)dv.p, (const int32_t*)nullptr, (int64_t)NP, bc, (pw_overlap_band*)dout.p);
   // chunks of pairs whose histograms fit 2^30 counters
   std::vector<uint64_t> h_hbase((size_t)NP), h_soff((size_t)NP), h_hsize((size_t)NP);
   OV_CHECK(hipMemcpy(h_hbase.data(), hbase.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
