@@ -1,27 +1,41 @@
 #!/usr/bin/env python
 """Headline benchmark: GCUPS of banded local alignment (BASELINE.json config 2) on N MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path (fill + end-cell search + traceback, pw_batch_solve +
-pw_batch_traceback) over one batch of 10 000 synthetic 2 kb x ~2 kb pairs, band radius 200, B_LOCAL,
-scores match 1 / mismatch -3 / gap open -5 / gap extend -2, inputs resident in HBM.  With N > 1 every
-rank holds its own batch of the same shape (pairs dealt round-robin from an N-times larger job: weak
-scaling) and each step ends with the gather of the 32-byte result records to rank 0 over RCCL.  Two batches of
-that shape are kept in flight per GPU, each on its own HIP stream, consecutive steps alternating between them
+With N > 1 and no torch.distributed environment the script starts N child ranks itself (``python -m
+torch.distributed.run`` as a subprocess, before anything touches a GPU); under ``torch.distributed.run`` it is one
+rank.  It needs N visible devices and says so if there are fewer.
+
+One "step" = one pass of the hot path (fill + end-cell search + traceback: pw_batch_solve + pw_batch_traceback) over
+one batch of 10 000 synthetic 2 kb x ~2 kb pairs, band radius 200, B_LOCAL, scores match 1 / mismatch -3 / gap open -5 /
+gap extend -2, inputs resident in HBM.  With N > 1 every rank holds its own batch of the same shape (pairs dealt
+round-robin from an N-times larger job: weak scaling) and each step ends with the gather of the 32-byte result records
+AND of the transcript slots to rank 0 over RCCL.  Two batches are kept in flight per GPU, each on its own HIP stream
 (--inflight): the traceback is a latency-bound walk, and the other batch's fill hides it.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the fill kernel (the dominant kernel) with the
-algorithmic bytes of SURVEY.md 8d -- 0.5 B per cell (4-bit tie mask) + X + Y + 32 B per pair + the
-transcript bytes -- over its mean duration measured with HIP events on the launch stream inside the
-library.  `cpu_baseline` times the reference pwlib itself (oracle/_ref, compiled from the reference
-sources) -- or the oracle restatement if that file is absent -- on the host cores, on a bounded sample
-of the same workload.
+Prints ONE JSON line (rank 0):
+  value / ms_per_step     the timed K steps (all ranks, max over ranks)
+  roofline                the fill kernel (the dominant kernel) priced with the algorithmic bytes of SURVEY.md 8d --
+                          0.5 B per cell (4-bit tie mask) + X + Y + 32 B per pair + the transcript bytes -- over its
+                          mean duration, HIP events recorded by the library on the launch stream while one batch runs
+                          alone (the `serial` leg: this is the figure a rocprofv3 --kernel-trace of
+                          `bench.py --inflight 1` shows); `frac_timed_region` prices the same bytes over the timed
+                          region's wall time per step instead
+  serial                  the same steps with one batch in flight
+  e2e_with_h2d_d2h        steps that also upload the sequences from pinned host memory and bring records and
+                          transcripts back; never `value`
+  variants                the 32-bit kernel (the like-for-like width of the reference's integer results) and the
+                          linear-gap rerun (go 0) on the same pairs; config 1 through the four drop-in calls
+  check                   what was verified about the batches the clock ran on
+  cpu_baseline            the reference pwlib itself (oracle/_ref) -- or the oracle restatement -- on the host cores,
+                          bounded sample of the same batch; its outputs are the `check.vs_reference` comparison
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,63 +48,70 @@ import numpy as np  # noqa: E402
 PAIRS, LENGTH, RADIUS = 10000, 2000, 200
 SCORES = dict(match=1., mismatch=-3., go=-5., ge=-2.)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CPU_SAMPLE_PER_CORE = 64
+
+
+def batch_seed(rank, j):
+    return 2 + 1000 * rank + 100 * j
 
 
 # ---------------------------------------------------------------------------------------------------
-# CPU baseline (rank 0, N == 1): the reference library on the host cores, bounded sample
+# CPU baseline (rank 0, N == 1): the reference library on the host cores, bounded sample of batch 0
 # ---------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    kind, seed, first, count, budget_s = args
+    kind, first, origins, mutants, budget_s = args
     sys.path.insert(0, ROOT)
     from biseqt_amd import synth
-    origins, mutants = synth.pair_batch(seed, first + count, LENGTH)
     cells = 0
+    out = []
     t0 = time.time()
-    done = 0
     if kind == 'reference':
         from oracle import ref_driver as R
         lib = R.load()
         devnull = os.open(os.devnull, os.O_WRONLY)
         os.dup2(devnull, 1)           # the reference prints band messages to stdout
-        for k in range(first, first + count):
+        for k in range(len(origins)):
             P = R.Problem(origins[k].tolist(), mutants[k].tolist(), mode=R.BANDED_MODE, alntype=R.B_LOCAL,
                           diag_range=(-RADIUS, RADIUS), L=4, **SCORES)
-            R.run(lib, P)              # init + solve + traceback + free, as pw.py drives it
+            r = R.run(lib, P)          # init + solve + traceback + free, as pw.py drives it
+            out.append((first + k, r['score'], tuple(r['opt']), r['transcript'], r['origin_idx'], r['mutant_idx']))
             cells += synth.banded_cells(len(origins[k]), len(mutants[k]), -RADIUS, RADIUS)
-            done += 1
             if time.time() - t0 > budget_s:
                 break
     else:
         from oracle import oracle as O
-        for k in range(first, first + count):
-            O.solve(origins[k], mutants[k], L=4, mode=1, alntype=O.B_LOCAL, diag_range=(-RADIUS, RADIUS), **SCORES)
+        for k in range(len(origins)):
+            r = O.solve(origins[k], mutants[k], L=4, mode=1, alntype=O.B_LOCAL, diag_range=(-RADIUS, RADIUS), **SCORES)
+            out.append((first + k, r['score'], tuple(r['opt']), r['transcript'], r['origin_idx'], r['mutant_idx']))
             cells += synth.banded_cells(len(origins[k]), len(mutants[k]), -RADIUS, RADIUS)
-            done += 1
             if time.time() - t0 > budget_s:
                 break
-    return cells, done, time.time() - t0
+    return cells, out, time.time() - t0
 
 
-def cpu_baseline(budget_s=12.0):
+def cpu_baseline(origins, mutants, budget_s=12.0):
+    """Times the reference on the first pairs of the batch the GPU will run; returns (json object, reference answers)."""
     import multiprocessing as mp
     kind = 'reference' if os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'pwlib_ref.so')) else 'port'
     if kind == 'port':
         from oracle import oracle as O
         O.lib()
     cores = min(os.cpu_count() or 1, 16)
-    per = 64
+    per = min(CPU_SAMPLE_PER_CORE, max(1, len(origins) // cores))
     ctx = mp.get_context('spawn')     # never fork a process that may touch the GPU
     t0 = time.time()
     with ctx.Pool(cores) as pool:
-        out = pool.map(_cpu_worker, [(kind, 2, c * per, per, budget_s) for c in range(cores)])
+        out = pool.map(_cpu_worker, [(kind, c * per, origins[c * per:(c + 1) * per], mutants[c * per:(c + 1) * per], budget_s)
+                                     for c in range(cores)])
     wall = time.time() - t0
     cells = sum(o[0] for o in out)
-    npairs = sum(o[1] for o in out)
+    answers = [a for o in out for a in o[1]]
     busy = max(o[2] for o in out)
-    return dict(value=cells / busy / 1e9, unit='GCUPS', cores=cores, kind=kind,
-                sample='%d pairs of the cfg2 batch (2 kb x ~2 kb, band radius 200, B_LOCAL), %d single-threaded '
-                       'processes, init+solve+traceback+free per pair, %.1f s busy / %.1f s wall'
-                       % (npairs, cores, busy, wall))
+    obj = dict(value=cells / busy / 1e9, unit='GCUPS', cores=cores, kind=kind,
+               sample='%d pairs of the timed cfg2 batch (2 kb x ~2 kb, band radius 200, B_LOCAL), %d single-threaded '
+                      'processes, init+solve+traceback+free per pair, %.1f s busy / %.1f s wall'
+                      % (len(answers), cores, busy, wall))
+    return obj, answers
 
 
 def pmc_traffic(kernel, pairs):
@@ -108,6 +129,27 @@ def pmc_traffic(kernel, pairs):
     return None
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 without a torch.distributed environment: start the N ranks as children.  Nothing in this process
+    has touched a GPU yet (counting devices does not initialise one on this image)."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write('bench.py: --gpus %d needs %d visible devices, this machine shows %d\n' % (args.gpus, args.gpus, have))
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
+
+
 # ---------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -117,26 +159,37 @@ def main():
     ap.add_argument('--pairs', type=int, default=PAIRS, help='pairs per GPU (default: the BASELINE config)')
     ap.add_argument('--inflight', type=int, default=2,
                     help='batches in flight per GPU, each on its own HIP stream (consecutive steps alternate); 2 hides the '
-                         'latency-bound traceback of one batch behind the fill of the next (measured: 4.53 -> 3.88 ms/step)')
+                         'latency-bound traceback of one batch behind the fill of the next')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the serial / e2e / variant legs (profiling runs)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL gather path even with one rank (self-test)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world))
 
-    cpu = None
+    from biseqt_amd import synth, verify
+    n_local = args.pairs
+    nfl = max(1, args.inflight)
+    seqs = [synth.pair_batch(batch_seed(rank, j), n_local, LENGTH) for j in range(nfl)]
+
+    cpu, ref_answers = None, []
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()           # before anything touches the GPU
+        cpu, ref_answers = cpu_baseline(seqs[0][0], seqs[0][1])     # before anything touches the GPU
 
     import torch
     import torch.distributed as dist
     from biseqt_amd import _pwlib as W
-    from biseqt_amd import synth
-    from biseqt_amd.batch import BatchAligner, RESULT_DTYPE
+    from biseqt_amd.batch import BatchAligner, PinnedArray, RESULT_DTYPE
+    from biseqt_amd import distributed as D
 
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit('bench.py: rank %d needs device %d, %d visible' % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
@@ -145,23 +198,23 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29513')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
+    akw = dict(alnmode=W.BANDED_MODE, alntype=W.B_LOCAL, alphabet_len=4, diag_range=(-RADIUS, RADIUS),
+               match_score=SCORES['match'], mismatch_score=SCORES['mismatch'], go_score=SCORES['go'],
+               ge_score=SCORES['ge'], device=local_rank)
     # rank r owns pairs r, r + world, ... of a job of world * pairs pairs (round-robin shard).  `inflight` batches
     # of that shape (different synthetic pairs) are resident; step i runs batch i % inflight on stream i % inflight.
-    n_local = args.pairs
-    nfl = max(1, args.inflight)
-    batches, streams = [], []
-    for j in range(nfl):
-        origins, mutants = synth.pair_batch(2 + 1000 * rank + 100 * j, n_local, LENGTH)
-        batches.append(BatchAligner(list(zip(origins, mutants)), alnmode=W.BANDED_MODE, alntype=W.B_LOCAL, alphabet_len=4,
-                                    diag_range=(-RADIUS, RADIUS), match_score=SCORES['match'],
-                                    mismatch_score=SCORES['mismatch'], go_score=SCORES['go'], ge_score=SCORES['ge'],
-                                    device=local_rank, flags=W.PW_FLAG_PROFILE))
-        streams.append(torch.cuda.Stream(device=dev))
+    batches = [BatchAligner(list(zip(*seqs[j])), flags=W.PW_FLAG_PROFILE, **akw) for j in range(nfl)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nfl)]
     batch = batches[0]
     cells = batch.cells
-    res_devs = [torch.as_tensor(b.results_device(), device=dev) for b in batches] if use_dist else None
-    gathered = [[torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(nfl)] \
-        if (use_dist and rank == 0) else None
+    res_devs = tx_devs = gathered = gathered_tx = None
+    if use_dist:
+        res_devs = [torch.as_tensor(b.results_device(), device=dev) for b in batches]
+        tx_devs = [torch.as_tensor(b.transcripts_device(), device=dev) for b in batches]
+        tx_sizes = [D.exchange_sizes(b.transcripts_bytes, rank, world, device=dev) for b in batches]
+        if rank == 0:
+            gathered = [[torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(nfl)]
+            gathered_tx = [[torch.empty(tx_sizes[j][r], dtype=torch.uint8, device=dev) for r in range(world)] for j in range(nfl)]
 
     def step(i):
         j = i % nfl
@@ -170,7 +223,9 @@ def main():
             batches[j].solve(s)
             batches[j].traceback(s)
             if use_dist:
+                # the single gather of scores and tracebacks (north star): 32-byte records, then the transcript slots
                 dist.gather(res_devs[j], gathered[j] if rank == 0 else None, dst=0)
+                D.gather_ragged_wait(D.gather_ragged_start(tx_devs[j], gathered_tx[j] if rank == 0 else None, rank, world))
         return batches[j].cells
 
     def fence():
@@ -181,25 +236,15 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    fill_ms, trace_ms = [], []
     done_cells = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         done_cells += step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    # fill-kernel duration of the LAST timed step of each batch (HIP events on its stream): with two batches in flight
-    # the two fills co-run, so each takes about twice as long as alone while two complete per that time
+    # fill-kernel duration of the LAST timed step of each batch: with two batches in flight the fills co-run
     overlapped_ms = [b.fill_ms() for b in batches[:min(nfl, args.steps)]]
-    # per-kernel durations (HIP events recorded by the library on the launch stream): sample a few extra steps of
-    # ONE batch alone, outside the timed region, so that the kernel time is not stretched by the other batch
-    stream = streams[0].cuda_stream
-    for _ in range(min(5, max(1, args.steps))):
-        batch.solve(stream)
-        batch.traceback(stream)
-        batch.sync(stream)
-        fill_ms.append(batch.fill_ms())
-        trace_ms.append(batch.trace_ms())
+
     t = torch.tensor([elapsed, float(done_cells)], dtype=torch.float64, device=dev)
     if use_dist:
         tm = t[:1].clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -208,20 +253,157 @@ def main():
     else:
         total_done = float(done_cells)
 
-    res = batch.results()
-    tx_bytes = int(res['tx_len'].sum())
-    alg_bytes = batch.algorithmic_bytes + tx_bytes
+    # ---- what the clock ran on, checked: every transcript of every timed batch re-scored on the host ------------
+    check = {}
+    results, transcripts = [], []
+    n_bad = 0
+    for j, b in enumerate(batches):
+        res = b.results()
+        txs = b.transcripts(res)
+        results.append(res); transcripts.append(txs)
+        traced = bool(((res['status'] & 1) == 1).all() and (res['opt_i'] >= 0).all())
+        bad = verify.check_batch(seqs[j][0], seqs[j][1], res, txs, SCORES['match'], SCORES['mismatch'], SCORES['go'],
+                                 SCORES['ge'], banded=True, dmins=[-RADIUS] * n_local)
+        n_bad += len(bad) + (0 if traced else 1)
+    check['rescored_pairs'] = n_local * nfl
+    check['rescore_failures'] = n_bad
+    n_ref_bad = 0
+    for (k, score, opt, tx, oi, mi) in ref_answers:             # rank 0, N == 1: the reference's own answers
+        r = results[0][k]
+        if not (r['score'] == score and (int(r['opt_i']), int(r['opt_j'])) == tuple(opt) and transcripts[0][k] == tx
+                and (int(r['origin_idx']), int(r['mutant_idx'])) == (oi, mi)):
+            n_ref_bad += 1
+    check['vs_reference_pairs'] = len(ref_answers)
+    check['vs_reference_mismatches'] = n_ref_bad
+    if use_dist:
+        bad_t = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(bad_t, op=dist.ReduceOp.SUM)
+        check['rescore_failures'] = int(bad_t.item())
+        check['rescored_pairs'] = n_local * nfl * world
+        if rank == 0:
+            # what arrived at the root: rank 0's own records bit for bit, and the last rank's records + transcripts,
+            # regenerated here from its seed and re-scored
+            last_j = (args.steps - 1) % nfl if args.steps else 0
+            got0 = gathered[last_j][0].cpu().numpy().view(RESULT_DTYPE)
+            gather_ok = bool((got0 == results[last_j]).all())
+            r_last = world - 1
+            if r_last > 0:
+                o_l, m_l = synth.pair_batch(batch_seed(r_last, last_j), n_local, LENGTH)
+                rec_l = gathered[last_j][r_last].cpu().numpy().view(RESULT_DTYPE)
+                slots = gathered_tx[last_j][r_last].cpu().numpy()
+                # the slot layout is a function of the lengths alone (pw_batch_tx_slot): cap = X + Y + 1, 16-byte aligned
+                caps = np.array([len(o) + len(m) + 1 for o, m in zip(o_l, m_l)], np.int64)
+                offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16)[:-1]])
+                txs_l = [slots[offs[k] + caps[k] - rec_l['tx_len'][k]: offs[k] + caps[k]].tobytes().decode('ascii')
+                         for k in range(n_local)]
+                gather_ok = gather_ok and verify.check_batch(o_l, m_l, rec_l, txs_l, SCORES['match'], SCORES['mismatch'],
+                                                             SCORES['go'], SCORES['ge'], banded=True,
+                                                             dmins=[-RADIUS] * n_local) == []
+            check['gathered_records_and_transcripts_ok'] = gather_ok
+    ok = check['rescore_failures'] == 0 and n_ref_bad == 0 and check.get('gathered_records_and_transcripts_ok', True)
+
+    # ---- extra legs (outside the timed region) ----------------------------------------------------------------------
+    extras = {}
+    stream0 = streams[0].cuda_stream
+    nx = max(3, min(10, args.steps))
+    # (1) serial: one batch in flight; the library's HIP events on the launch stream give the fill kernel alone
+    fill_ms, trace_ms = [], []
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(nx):
+        batch.solve(stream0); batch.traceback(stream0); batch.sync(stream0)
+        fill_ms.append(batch.fill_ms()); trace_ms.append(batch.trace_ms())
+    serial_ms = (time.perf_counter() - t1) / nx * 1e3
     fill = float(np.mean(fill_ms))
-    # parity spot check inside the bench: re-score a few transcripts (cheap, size-independent)
-    ok = bool((res['status'] & 1).all() and (res['opt_i'] >= 0).all())
+    tx_bytes = int(results[0]['tx_len'].sum())
+    alg_bytes = batch.algorithmic_bytes + tx_bytes
+    extras['serial'] = {'batches_in_flight': 1, 'ms_per_step': round(serial_ms, 4), 'gcups': round(cells / serial_ms / 1e6, 2)}
+    variants = {}
+    if not args.no_extras and rank == 0:
+        # (2) end to end with the host boundary: H2D of the sequence arena, fill, traceback, D2H of records + transcripts
+        pins = []
+        for b in batches:
+            pa = PinnedArray(b.arena.nbytes); pa.array[:] = b.arena
+            pins.append((pa, PinnedArray(32 * n_local), PinnedArray(b.transcripts_bytes)))
+
+        def e2e_step(i):
+            j = i % nfl
+            s = streams[j].cuda_stream
+            pa, pr, pt = pins[j]
+            batches[j].upload_async(pa, s)
+            batches[j].solve(s); batches[j].traceback(s)
+            batches[j].results_async(pr, s); batches[j].transcripts_async(pt, s)
+
+        for i in range(2):
+            e2e_step(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nx):
+            e2e_step(i)
+        torch.cuda.synchronize()
+        e2e_ms = (time.perf_counter() - t1) / nx * 1e3
+        back = pins[(nx - 1) % nfl][1].array.view(RESULT_DTYPE)
+        extras['e2e_with_h2d_d2h'] = {
+            'ms_per_step': round(e2e_ms, 4), 'gcups': round(cells / e2e_ms / 1e6, 2), 'batches_in_flight': nfl,
+            'h2d_bytes': int(batch.arena.nbytes), 'd2h_bytes': int(32 * n_local + batch.transcripts_bytes),
+            'host_memory': 'pinned (pw_host_alloc)', 'records_equal_resident_run': bool((back == results[(nx - 1) % nfl]).all())}
+        ok = ok and extras['e2e_with_h2d_d2h']['records_equal_resident_run']
+        for pa, pr, pt in pins:
+            pa.close(); pr.close(); pt.close()
+        # (3) the same pairs through the 32-bit kernel, and with linear gaps (go 0), each checked by re-scoring
+        for name, flags, go in (('int32_kernel', W.PW_FLAG_NO_PACKED16 | W.PW_FLAG_PROFILE, SCORES['go']),
+                                ('linear_gap_go0', W.PW_FLAG_PROFILE, 0.0)):
+            kw2 = dict(akw); kw2['go_score'] = go
+            with BatchAligner(list(zip(*seqs[0])), flags=flags, **kw2) as b2:
+                fm, wall = [], []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    b2.solve(stream0); b2.traceback(stream0); b2.sync(stream0)
+                    wall.append((time.perf_counter() - t1) * 1e3); fm.append(b2.fill_ms())
+                r2 = b2.results(); x2 = b2.transcripts(r2)
+                f2 = float(np.mean(fm[1:])); ab2 = b2.algorithmic_bytes + int(r2['tx_len'].sum())
+                bad2 = verify.check_batch(seqs[0][0], seqs[0][1], r2, x2, SCORES['match'], SCORES['mismatch'], go,
+                                          SCORES['ge'], banded=True, dmins=[-RADIUS] * n_local)
+                same = bool((r2 == results[0]).all()) if go == SCORES['go'] else None
+                variants[name] = {'kernel': b2.kernel_name, 'kernel_ms': round(f2, 4), 'kernel_gcups': round(cells / f2 / 1e6, 2),
+                                  'hbm_frac': round(ab2 / (f2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                  'ms_per_step_serial': round(float(np.mean(wall[1:])), 4),
+                                  'gcups_serial': round(cells / float(np.mean(wall[1:])) / 1e6, 2),
+                                  'rescore_failures': len(bad2)}
+                if same is not None:
+                    variants[name]['records_equal_packed16_run'] = same
+                    ok = ok and same
+                ok = ok and not bad2
+        # (4) BASELINE config 1 through the four drop-in calls (1 kb x 1 kb GLOBAL, default scores and 1/-3/-5/-2)
+        from biseqt_amd.pw import Aligner
+        from biseqt_amd.sequence import Alphabet
+        A = Alphabet('ACGT')
+        rng = synth.rng_for(1)
+        s1 = A.parse(''.join('ACGT'[c] for c in synth.rand_seqs(rng, 1, 1000)[0]))
+        s2 = A.parse(''.join('ACGT'[c] for c in synth.rand_seqs(rng, 1, 1000)[0]))
+        cfg1 = {}
+        for name, kw1 in (('default_scores', {}), ('scores_1_-3_-5_-2', dict(match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2))):
+            ms = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                with Aligner(s1, s2, alnmode=W.STD_MODE, alntype=W.GLOBAL, **kw1) as al:
+                    sc = al.solve()
+                    aln = al.traceback()
+                ms.append((time.perf_counter() - t1) * 1e3)
+                rescored = al.calculate_score(aln)
+            cfg1[name] = {'ms_init_solve_traceback_free': round(min(ms), 3), 'score': sc, 'rescored': rescored}
+            ok = ok and rescored == sc
+        variants['config1_dropin_1kb_global'] = cfg1
 
     if rank == 0:
         value = total_done / elapsed / 1e9          # cells of every step of every rank / max-over-ranks time
+        ms_step = elapsed / args.steps * 1e3
         achieved = alg_bytes / (fill * 1e-3) / 1e9
         line = {
             'metric': 'GCUPS (DP cell updates/s) banded local align',
             'value': round(value, 3), 'unit': 'GCUPS', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+            'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             # the arithmetic the dominant kernel computes in: packed 16-bit lanes for k_fill16, else i32 / f64
             'dtype': 'i16' if 'k_fill16' in batch.kernel_name else ('i32' if batch.score_dtype == 'i32' else 'f64'),
@@ -230,29 +412,35 @@ def main():
                                    'match 1 / mismatch -3 / go -5 / ge -2, fill + end-cell search + traceback%s; '
                                    '%d batches in flight per GPU on separate HIP streams'
                                    % (n_local, LENGTH, LENGTH, RADIUS,
-                                      ' + RCCL gather of result records' if world > 1 else '', nfl),
-                       'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'batches_in_flight': nfl, 'parallelism': 'pairs round-robin x%d' % world},
+                                      ' + RCCL gather of result records and transcripts to rank 0' if world > 1 else '', nfl),
+                       'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'batches_in_flight': nfl,
+                       'parallelism': 'pairs round-robin x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(batch.kernel_name, n_local),
                          'kernel': batch.kernel_name,
-                         'kernel_ms': round(fill, 4), 'kernel_ms_note': 'one batch running alone (5 extra steps after the '
-                         'timed region); in the timed region %d fills co-run, each lasting %s ms' % (nfl, '/'.join('%.2f' % v for v in overlapped_ms)),
+                         'kernel_ms': round(fill, 4),
+                         'kernel_ms_note': 'HIP events on the launch stream, mean of %d launches of one batch running alone '
+                                           '(serial leg); in the timed region %d fills co-run, each lasting %s ms'
+                                           % (nx, nfl, '/'.join('%.2f' % v for v in overlapped_ms)),
                          'algorithmic_bytes_per_launch': int(alg_bytes),
                          'kernel_gcups': round(cells / (fill * 1e-3) / 1e9, 2),
+                         'frac_timed_region': round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          'traceback_kernel_ms': round(float(np.mean(trace_ms)), 4)},
-            'results_ok': ok,
+            'results_ok': bool(ok), 'check': check,
         }
+        line.update(extras)
+        if variants:
+            line['variants'] = variants
         if cpu is not None:
             line['cpu_baseline'] = cpu
         print(json.dumps(line))
-    if use_dist and rank == 0:
-        # the gathered records of rank 0 must be this rank's device records, bit for bit
-        got = gathered[0][0].cpu().numpy().view(RESULT_DTYPE)
-        assert (got == res).all(), 'gathered records differ from the local results'
     for b in batches:
         b.close()
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        sys.exit('bench.py: result check FAILED: %s' % json.dumps(check))
 
 
 if __name__ == '__main__':

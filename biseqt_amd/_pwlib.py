@@ -115,7 +115,8 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_last_error', 'pw_device_count', 'pw_pool_trim', 'pw_batch_create', 'pw_batch_destroy',
            'pw_batch_init_rc', 'pw_batch_band', 'pw_batch_pair_cells', 'pw_batch_cells',
            'pw_batch_algorithmic_bytes', 'pw_batch_score_type', 'pw_batch_kernel_name', 'pw_batch_upload_arena',
-           'pw_batch_arena_device', 'pw_batch_solve', 'pw_batch_traceback',
+           'pw_batch_arena_device', 'pw_host_alloc', 'pw_host_free', 'pw_batch_upload_arena_async',
+           'pw_batch_results_async', 'pw_batch_transcripts_async', 'pw_batch_solve', 'pw_batch_traceback',
            'pw_batch_traceback_from', 'pw_batch_sync', 'pw_batch_results_device',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
            'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_table', 'pw_batch_fill_ms',
@@ -182,6 +183,13 @@ def load():
     lib.pw_batch_upload_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.pw_batch_arena_device.argtypes = [C.c_void_p]
     lib.pw_batch_arena_device.restype = C.c_void_p
+    lib.pw_host_alloc.argtypes = [C.c_uint64]
+    lib.pw_host_alloc.restype = C.c_void_p
+    lib.pw_host_free.argtypes = [C.c_void_p]
+    lib.pw_host_free.restype = None
+    lib.pw_batch_upload_arena_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.pw_batch_results_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pw_batch_transcripts_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pw_batch_solve.argtypes = [C.c_void_p, C.c_void_p]
     lib.pw_batch_traceback.argtypes = [C.c_void_p, C.c_void_p]
     lib.pw_batch_traceback_from.argtypes = [C.c_void_p, P(C.c_int32), C.c_void_p]

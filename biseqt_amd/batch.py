@@ -41,6 +41,32 @@ class DeviceBuffer(object):
         return dict(shape=(self.nbytes,), typestr='|u1', data=(self.ptr, False), version=2)
 
 
+class PinnedArray(object):
+    """Page-locked host memory (``pw_host_alloc``) viewed as a numpy array: the source / destination of the
+    asynchronous transfers (``upload_async``, ``results_async``, ``transcripts_async``)."""
+
+    def __init__(self, nbytes, dtype=np.uint8):
+        self.lib = W.load()
+        self.nbytes = int(nbytes)
+        self.ptr = self.lib.pw_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MemoryError('pw_host_alloc(%d) failed: %s' % (nbytes, W.last_error()))
+        buf = (C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=np.uint8, count=self.nbytes).view(dtype)
+
+    def close(self):
+        if getattr(self, 'ptr', None):
+            self.array = None
+            self.lib.pw_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 PAIR_DTYPE = np.dtype([('origin_off', '<u8'), ('mutant_off', '<u8'), ('origin_len', '<i4'), ('mutant_len', '<i4'),
                        ('dmin', '<i4'), ('dmax', '<i4')])
 assert PAIR_DTYPE.itemsize == 32
@@ -235,6 +261,23 @@ class BatchAligner(object):
         self._ck(self.lib.pw_batch_upload_arena(self.handle, self.arena.ctypes.data, self.arena.nbytes),
                  'pw_batch_upload_arena')
 
+    def upload_async(self, pinned, stream=None):
+        """H2D of the arena from a :class:`PinnedArray` holding it, asynchronous on ``stream``."""
+        self._ck(self.lib.pw_batch_upload_arena_async(self.handle, pinned.ptr, self.arena.nbytes, stream),
+                 'pw_batch_upload_arena_async')
+
+    def results_async(self, pinned, stream=None):
+        """D2H of the 32-byte records into a :class:`PinnedArray` (``32 * n`` bytes), asynchronous on ``stream``."""
+        self._ck(self.lib.pw_batch_results_async(self.handle, pinned.ptr, stream), 'pw_batch_results_async')
+
+    def transcripts_async(self, pinned, stream=None):
+        """D2H of all transcript slots into a :class:`PinnedArray` (``transcripts_bytes`` bytes), asynchronous."""
+        self._ck(self.lib.pw_batch_transcripts_async(self.handle, pinned.ptr, stream), 'pw_batch_transcripts_async')
+
+    @property
+    def transcripts_bytes(self):
+        return int(self.lib.pw_batch_transcripts_bytes(self.handle))
+
     def solve(self, stream=None):
         self._ck(self.lib.pw_batch_solve(self.handle, stream), 'pw_batch_solve')
 
@@ -263,12 +306,16 @@ class BatchAligner(object):
         self._ck(self.lib.pw_batch_results(self.handle, out.ctypes.data), 'pw_batch_results')
         return out[:self.n]
 
-    def transcripts(self, results=None):
-        """List with one transcript string (or None) per pair (synchronous D2H)."""
+    def transcripts(self, results=None, slots=None):
+        """List with one transcript string (or None) per pair (synchronous D2H, unless ``slots`` already holds the
+        slot buffer, e.g. from :meth:`transcripts_async`)."""
         res = self.results() if results is None else results
         nb = self.lib.pw_batch_transcripts_bytes(self.handle)
-        buf = np.zeros(max(nb, 1), np.uint8)
-        self._ck(self.lib.pw_batch_transcripts(self.handle, buf.ctypes.data), 'pw_batch_transcripts')
+        if slots is not None:
+            buf = slots
+        else:
+            buf = np.zeros(max(nb, 1), np.uint8)
+            self._ck(self.lib.pw_batch_transcripts(self.handle, buf.ctypes.data), 'pw_batch_transcripts')
         out = []
         off, cap = C.c_uint64(), C.c_int32()
         for k in range(self.n):

@@ -551,7 +551,7 @@ struct WaveFill {
 // Blocks in which diagonals start or end run a slightly longer packed body (cellpair<EDGE = true>) that
 // needs no predication at all -- see there.  Eligibility (host planner): LOCAL and B_LOCAL (begin anywhere,
 // end anywhere: the end-cell search uses the tracked bests only), match/mismatch scoring, go <= 0, every
-// score within +-100, min(X,Y) * match <= 8000 (below the 8192-deep sentinel that blocks the first diagonal
+// score within +-100, min(X,Y) * max(match, mismatch, 0) <= 8000 (below the 8192-deep sentinel that blocks the first diagonal
 // above the band), X + Y + 2 < 32000 (steps as signed 16-bit).
 // =================================================================================================
 // 16-byte group of the mask plane; an 8-byte store at any byte address

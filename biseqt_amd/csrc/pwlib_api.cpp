@@ -33,37 +33,72 @@ int env_int(const char* name, int dflt);
 
 // A small cache of the big device buffers (tie-mask planes, transcript slots): freeing and re-allocating tens of GB per
 // batch stalls in the driver for seconds at a time (measured in the config-4 alignment stage).  Buffers of at least
-// 1 MB are kept on pw_batch_destroy, up to PWLIB_POOL_GB in total (default 64; 0 disables), and handed to the next
-// batch that fits within a factor of two.  pw_pool_trim() releases everything.
+// 1 MB are kept on pw_batch_destroy, per device up to PWLIB_POOL_GB (default: a quarter of the device's memory; 0
+// disables), and handed to the next batch on that device that fits.  pw_pool_trim() releases everything.
 struct PoolEntry { void* p; size_t bytes; int device; };
 std::mutex g_pool_mutex;
 std::vector<PoolEntry> g_pool;
-size_t g_pool_held = 0;
+constexpr int kMaxDevices = 64;
+size_t g_pool_held[kMaxDevices] = {0};     // bytes parked per device
+size_t g_pool_cap[kMaxDevices] = {0};      // 0 = not computed yet
+
+// Cap of the bytes parked on one device: PWLIB_POOL_GB if set (0 disables the pool), otherwise a quarter of the
+// device's memory (72 GB on an MI355X), read once per device.
+size_t pool_cap(int device) {
+  if (device < 0 || device >= kMaxDevices) return 0;
+  if (g_pool_cap[device] == 0) {
+    const char* v = getenv("PWLIB_POOL_GB");
+    size_t cap;
+    if (v && *v) cap = (size_t)atoi(v) << 30;
+    else {
+      size_t fr = 0, tot = 0;
+      cap = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? tot / 4 : ((size_t)16 << 30);
+    }
+    g_pool_cap[device] = cap + 1;            // + 1: "computed" even when the cap itself is 0
+  }
+  return g_pool_cap[device] - 1;
+}
 
 void* pool_take(int device, size_t bytes, size_t* got) {
   std::lock_guard<std::mutex> lk(g_pool_mutex);
   int best = -1;
+  // a parked buffer may be up to 25 % (+ 1 MB) larger than asked for: batches of one chunked job differ by less
   for (int i = 0; i < (int)g_pool.size(); i++)
-    if (g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= 2 * bytes + (1u << 20) &&
+    if (g_pool[i].device == device && g_pool[i].bytes >= bytes && g_pool[i].bytes <= bytes + bytes / 4 + (1u << 20) &&
         (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
   if (best < 0) return nullptr;
   void* p = g_pool[best].p; *got = g_pool[best].bytes;
-  g_pool_held -= g_pool[best].bytes;
+  if (device >= 0 && device < kMaxDevices) g_pool_held[device] -= g_pool[best].bytes;
   g_pool.erase(g_pool.begin() + best);
   return p;
 }
+// (the caller has made sure no kernel still uses p: batch_free_device synchronises first)
 void pool_give(int device, void* p, size_t bytes) {
   if (!p) return;
-  const size_t cap = (size_t)env_int("PWLIB_POOL_GB", 64) << 30;
-  {
+  if (device >= 0 && device < kMaxDevices && bytes >= (1u << 20)) {
+    const size_t cap = pool_cap(device);
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    if (bytes >= (1u << 20) && g_pool_held + bytes <= cap && g_pool.size() < 32) {
+    if (g_pool_held[device] + bytes <= cap && g_pool.size() < 64) {
       g_pool.push_back(PoolEntry{p, bytes, device});
-      g_pool_held += bytes;
+      g_pool_held[device] += bytes;
       return;
     }
   }
   (void)hipFree(p);
+}
+void pool_drop(int device /* < 0: every device */) {
+  std::vector<PoolEntry> drop;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    std::vector<PoolEntry> keep;
+    for (auto& e : g_pool) (device < 0 || e.device == device ? drop : keep).push_back(e);
+    g_pool.swap(keep);
+    for (int d = 0; d < kMaxDevices; d++) if (device < 0 || d == device) g_pool_held[d] = 0;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto& d : drop) { (void)hipSetDevice(d.device); (void)hipFree(d.p); }
+  (void)hipSetDevice(cur);
 }
 hipError_t pool_alloc(int device, void** p, size_t bytes, size_t* got) {
   // size classes, 8 per octave: consecutive batches of similar size then reuse each other's buffers
@@ -78,9 +113,7 @@ hipError_t pool_alloc(int device, void** p, size_t bytes, size_t* got) {
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {           // out of memory with buffers parked in the pool: release them and retry once
     (void)hipGetLastError();
-    std::vector<PoolEntry> drop;
-    { std::lock_guard<std::mutex> lk(g_pool_mutex); drop.swap(g_pool); g_pool_held = 0; }
-    for (auto& d : drop) (void)hipFree(d.p);
+    pool_drop(device);
     e = hipMalloc(p, bytes);
   }
   return e;
@@ -143,6 +176,9 @@ namespace {
 int batch_free_device(pw_batch* b) {
   if (!b) return 0;
   (void)hipSetDevice(b->device);
+  // the buffers are parked for the next batch, not freed (hipFree would synchronise by itself): make sure nothing that
+  // was launched on any stream still reads or writes them
+  (void)hipDeviceSynchronize();
   for (auto& c : b->classes) if (c.d_order) (void)hipFree(c.d_order);
   pool_give(b->device, b->d_arena, b->arena_alloc);
   pool_give(b->device, b->d_pairs, b->pairs_alloc);
@@ -239,7 +275,8 @@ int batch_build(pw_batch* b) {
   else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_EDGE && b->endrule == pw::END_BANDED_OVERLAP) prule = 1;
   else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
   bool pfits = false;
-  if (prule == 0) pfits = (double)maxmin * std::max(mt, 0.0) <= 8000;
+  // (any substitution may be the best one: the API accepts mismatch > match)
+  if (prule == 0) pfits = (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 8000;
   else if (prule > 0) {
     // real scores must stay above the values derived from the sentinel (<= -24000 + 100) and below int16's top
     const double worst = std::max(0.0, -std::min(mt, mm));
@@ -442,11 +479,7 @@ extern "C" {
 
 const char* pw_last_error(void) { return g_err.c_str(); }
 
-void pw_pool_trim(void) {
-  std::vector<PoolEntry> drop;
-  { std::lock_guard<std::mutex> lk(g_pool_mutex); drop.swap(g_pool); g_pool_held = 0; }
-  for (auto& d : drop) { (void)hipSetDevice(d.device); (void)hipFree(d.p); }
-}
+void pw_pool_trim(void) { pool_drop(-1); }
 
 int pw_device_count(void) {
   int n = 0;
@@ -519,6 +552,30 @@ int pw_batch_upload_arena(pw_batch* b, const uint8_t* host, uint64_t bytes) {
 }
 
 void* pw_batch_arena_device(pw_batch* b) { return b->d_arena; }
+
+void* pw_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail("hipHostMalloc failed"); return nullptr; }
+  return p;
+}
+void pw_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int pw_batch_upload_arena_async(pw_batch* b, const uint8_t* host, uint64_t bytes, void* stream) {
+  if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
+  HIP_TRY(hipSetDevice(b->device));
+  if (bytes) HIP_TRY(hipMemcpyAsync(b->d_arena, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+int pw_batch_results_async(pw_batch* b, pw_result* out, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->n) HIP_TRY(hipMemcpyAsync(out, b->d_results, sizeof(pw_result) * (size_t)b->n, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+int pw_batch_transcripts_async(pw_batch* b, uint8_t* out, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (b->tx_bytes) HIP_TRY(hipMemcpyAsync(out, b->d_tx, b->tx_bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
 
 int pw_batch_solve(pw_batch* b, void* stream) {
   hipStream_t st = (hipStream_t)stream;

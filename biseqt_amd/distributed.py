@@ -109,3 +109,36 @@ def gather_bytes(local_bytes, rank, world, group=None):
     if rank != 0:
         return None
     return [chunks[r][:int(sizes[r].item())] for r in range(world)]
+
+
+def gather_ragged_start(local, recv, rank, world, group=None):
+    """The transcript gather of a step, with sizes agreed beforehand: rank r > 0 sends its uint8 tensor ``local``,
+    rank 0 receives it into the pre-allocated ``recv[r]`` (``recv[0]`` is not used: rank 0 keeps its own).  One grouped
+    send / receive -- the way RCCL itself builds a gather, each rank over its direct xGMI link to the root -- with no
+    size exchange, no padding copy and no host synchronisation.  Returns the requests; :func:`gather_ragged_wait`
+    orders the current stream behind them."""
+    import torch.distributed as dist
+    if world == 1:
+        return []
+    if rank == 0:
+        ops = [dist.P2POp(dist.irecv, recv[r], r, group) for r in range(1, world)]
+    else:
+        ops = [dist.P2POp(dist.isend, local, 0, group)]
+    return dist.batch_isend_irecv(ops)
+
+
+def gather_ragged_wait(reqs):
+    for r in reqs:
+        r.wait()
+
+
+def exchange_sizes(n_local, rank, world, device=None, group=None):
+    """Every rank's byte count, as a list of ints on every rank (once, at set-up time)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return [int(n_local)]
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return [int(o.item()) for o in out]

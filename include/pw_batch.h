@@ -70,12 +70,15 @@ int pw_device_count(void);
 /* Plans the batch (band clamp / feasibility per pair exactly as dptable_init), picks the kernel variants,
  * allocates every device buffer and uploads the descriptors.  The arena is `arena_bytes` long; its
  * contents are supplied later (pw_batch_upload_arena or pw_batch_arena_device).  NULL on error. */
-/* The library keeps the big device buffers of destroyed batches (>= 1 MB each, PWLIB_POOL_GB in total, default 64,
- * 0 disables) for the next batch; pw_pool_trim releases them. */
+/* The library keeps the big device buffers of destroyed batches (>= 1 MB each; per device up to PWLIB_POOL_GB, default a
+ * quarter of the device's memory, 0 disables) for the next batch on that device; pw_pool_trim releases them all -- call
+ * it before handing the GPU's memory to another allocator in the process (torch, RCCL). */
 void pw_pool_trim(void);
 
 pw_batch* pw_batch_create(int device, const pw_scoring* scoring, int32_t n_pairs, const pw_pair* pairs,
                           uint64_t arena_bytes, uint32_t flags);
+/* Waits for the device (every stream) before releasing or parking the batch's buffers, so a batch may be destroyed
+ * while its last launches are still in flight. */
 void pw_batch_destroy(pw_batch* b);
 
 /* per-pair planning results (host side, available right after create) */
@@ -89,6 +92,14 @@ const char* pw_batch_kernel_name(const pw_batch* b);                         /* 
 
 int pw_batch_upload_arena(pw_batch* b, const uint8_t* host_arena, uint64_t bytes);   /* synchronous H2D */
 void* pw_batch_arena_device(pw_batch* b);
+/* Pinned host memory for the asynchronous transfers below (hipHostMalloc / hipHostFree). */
+void* pw_host_alloc(uint64_t bytes);
+void pw_host_free(void* p);
+/* H2D of the arena / D2H of the records and transcript slots, asynchronous on `stream` (ordered with the kernels
+ * launched on it); host buffers should come from pw_host_alloc, the caller synchronises (pw_batch_sync). */
+int pw_batch_upload_arena_async(pw_batch* b, const uint8_t* host_arena, uint64_t bytes, void* stream);
+int pw_batch_results_async(pw_batch* b, pw_result* host_out, void* stream);
+int pw_batch_transcripts_async(pw_batch* b, uint8_t* host_out, void* stream);
 
 /* K1 (+ end-cell search): asynchronous on `stream`. */
 int pw_batch_solve(pw_batch* b, void* stream);

@@ -109,3 +109,48 @@ def test_two_rank_gloo_gather_of_overlap_band_records(tmp_path):
     full = np.load(os.path.join(str(tmp_path), 'bands.npy'))
     q = np.arange(n_total)
     assert (full['d_best'] == q * 3 - 7).all() and (full['w_best'] == q / 8.0).all() and (full['n_seeds'] == q + 1).all()
+
+
+def _worker_ragged(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    from biseqt_amd import distributed as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n = 1000 + 37 * rank                                     # ragged: every rank a different byte count
+    mine = torch.from_numpy(((np.arange(n) * (rank + 3)) % 251).astype(np.uint8))
+    sizes = D.exchange_sizes(n, rank, world)
+    assert sizes == [1000 + 37 * r for r in range(world)]
+    recv = [torch.zeros(s, dtype=torch.uint8) for s in sizes] if rank == 0 else None
+    for step in range(3):                                    # the same buffers every step, as bench.py does
+        D.gather_ragged_wait(D.gather_ragged_start(mine, recv, rank, world))
+    if rank == 0:
+        for r in range(1, world):
+            assert (recv[r].numpy() == ((np.arange(sizes[r]) * (r + 3)) % 251).astype(np.uint8)).all()
+        open(os.path.join(outdir, 'ok'), 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_ragged_transcript_gather(tmp_path):
+    """bench.py's per-step transcript gather: sizes agreed once, then one grouped send / receive per step."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_ragged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'ok'))
+
+
+def test_bench_self_launch_refuses_without_enough_devices():
+    """`python bench.py --gpus N` starts its N ranks itself; with fewer than N devices it says so and exits 2
+    (no assertion error, no GPU call)."""
+    import subprocess
+    import sys
+    import torch
+    have = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    want = max(have + 1, 2)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(want)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert p.returncode == 2
+    assert 'needs %d visible devices' % want in p.stderr

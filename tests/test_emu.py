@@ -101,7 +101,7 @@ def test_emu_packed16_local(oracle):
         m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 9))).astype(np.uint8)
         if rng.random() < 0.3:
             m = np.concatenate([rng.integers(0, L, int(rng.integers(0, 30))).astype(np.uint8), m])
-        kw = dict(L=L, match=float(rng.choice([1, 2, 5])), mismatch=float(rng.choice([0, -1, -3])),
+        kw = dict(L=L, match=float(rng.choice([1, 2, 5])), mismatch=float(rng.choice([0, -1, -3, 6])),   # also mismatch > match
                   go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
         if rng.random() < 0.7:
             r, c = int(rng.integers(1, 50)), int(rng.integers(-10, 10))

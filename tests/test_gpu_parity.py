@@ -4,6 +4,7 @@ properties at BASELINE config sizes.  Bit-exact for integer scores; for the floa
 scores the comparison is also exact (same IEEE double additions in the same association), which is
 stricter than the 3-decimals the reference's own tests ask for (tests/test_pw.py:126-135)."""
 import collections
+import hashlib
 import json
 import os
 
@@ -280,6 +281,7 @@ def test_config2_properties_full_size(oracle):
     with BatchAligner(list(zip(origins, mutants)), alnmode=1, alntype=1, alphabet_len=4,
                       diag_range=(-200, 200), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as b:
         assert b.score_dtype == 'i32'
+        assert b.kernel_name == 'k_fill16<8, false>'      # the kernel bench.py's headline line reports
         cells = b.cells
         res = b.run()
         txs = b.transcripts(res)
@@ -296,6 +298,88 @@ def test_config2_properties_full_size(oracle):
                          match=1, mismatch=-3, go=-5, ge=-2)
         assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score']
         assert txs[k] == r['transcript']
+
+
+def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
+    """The batch bench.py times -- 10 000 pairs, 2 kb x ~2 kb, band radius 200, B_LOCAL, 1/-3/-5/-2 -- with the six
+    config-sized golden pairs of that scoring embedded in it: the default run must use the kernel the bench reports,
+    every transcript must re-score to its score and end in the reported cell, the golden pairs must equal the
+    reference's answers, a sample must equal the oracle, and the 32-bit and f64 kernels must return the very same
+    records and transcripts for all 10 000 pairs."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth, verify
+    from biseqt_amd.batch import BatchAligner
+    n = 10000
+    origins, mutants = synth.pair_batch(2, n, 2000)
+    gold = [(k, rec) for k, rec in enumerate(load_golden('config_sized.json'))
+            if rec['kw'].get('alntype') == 1 and rec['kw'].get('mode') == 1 and rec['kw'].get('go') == -5.0]
+    assert len(gold) == 6
+    where = {}
+    for q, (k, rec) in enumerate(gold):
+        slot = 17 + 1613 * q
+        origins[slot] = np.array(dec(rec['origin']), np.uint8)
+        mutants[slot] = np.array(dec(rec['mutant']), np.uint8)
+        where[slot] = (k, rec)
+    pairs = list(zip(origins, mutants))
+    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-200, 200), match_score=1, mismatch_score=-3,
+              go_score=-5, ge_score=-2)
+    runs = {}
+    for name, flags in (('packed16', 0), ('int32', W.PW_FLAG_NO_PACKED16), ('f64', W.PW_FLAG_FORCE_F64)):
+        with BatchAligner(pairs, flags=flags, **kw) as b:
+            kname = b.kernel_name
+            res = b.run()
+            runs[name] = (kname, res.copy(), b.transcripts(res))
+    assert runs['packed16'][0] == 'k_fill16<8, false>'
+    assert runs['int32'][0] == 'k_fill<int, 8, true, true, false>'
+    assert runs['f64'][0] == 'k_fill<double, 8, true, true, false>'
+    kname, res, txs = runs['packed16']
+    assert (res['status'] == W.PW_ST_TRACED).all() and (res['opt_i'] >= 0).all()
+    assert verify.check_batch(origins, mutants, res, txs, 1, -3, -5, -2, banded=True, dmins=[-200] * n) == []
+    for slot, (k, rec) in where.items():
+        e = rec['expect']
+        assert (int(res['opt_i'][slot]), int(res['opt_j'][slot])) == tuple(e['opt']), k
+        assert res['score'][slot] == e['score'] and len(txs[slot]) == e['tx_len'], k
+        assert hashlib.sha256(txs[slot].encode()).hexdigest() == e['tx_sha256'], k
+        assert (int(res['origin_idx'][slot]), int(res['mutant_idx'][slot])) == (e['origin_idx'], e['mutant_idx']), k
+    for k in range(0, n, 157):                                 # 64 pairs against the oracle
+        r = oracle.solve(origins[k], mutants[k], L=4, mode=1, alntype=1, diag_range=(-200, 200),
+                         match=1, mismatch=-3, go=-5, ge=-2)
+        assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score'], k
+        assert txs[k] == r['transcript'], k
+    for other in ('int32', 'f64'):
+        _, res2, txs2 = runs[other]
+        assert (res2 == res).all(), other
+        assert txs2 == txs, other
+
+
+def test_packed16_admission_with_mismatch_above_match(oracle):
+    """A mismatch score above the match score bounds the running score by min(X, Y) * mismatch: a 7000 x 7000 local
+    band (36 221 at the optimum) must not take the 16-bit kernel, and a 1000 x 1000 one (bounded by 6000) may and
+    must still equal the 32-bit kernel and the oracle."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(242)
+    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-10, 10), match_score=1, mismatch_score=6,
+              go_score=-5, ge_score=-2)
+    for n, packed in ((7000, False), (1000, True)):
+        o = synth.rand_seqs(rng, 1, n)[0]
+        m = synth.rand_seqs(rng, 1, n)[0]
+        pairs = [(o, m)] * 300                              # enough pairs to leave latency mode
+        with BatchAligner(pairs, **kw) as b:
+            assert ('k_fill16' in b.kernel_name) == packed, b.kernel_name
+            res = b.run()
+            txs = b.transcripts(res)
+        with BatchAligner(pairs, flags=W.PW_FLAG_NO_PACKED16, **kw) as b:
+            assert 'k_fill16' not in b.kernel_name
+            res2 = b.run()
+            txs2 = b.transcripts(res2)
+        assert (res == res2).all() and txs == txs2
+        r = oracle.solve(o, m, L=4, mode=1, alntype=1, diag_range=(-10, 10), match=1, mismatch=6, go=-5, ge=-2)
+        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'] and res['score'][0] == r['score']
+        assert txs[0] == r['transcript']
+        if not packed:
+            assert r['score'] > 32767
 
 
 def test_traceback_from_explicit_end_cells(oracle):
