@@ -105,6 +105,7 @@ PW_ST_TRACED, PW_ST_EMPTY, PW_ST_PANICK = 1, 2, 4
 PW_FLAG_DUMP_SCORES, PW_FLAG_FORCE_F64, PW_FLAG_FORCE_GENERIC, PW_FLAG_PROFILE = 1, 2, 4, 8
 PW_FLAG_NO_PACKED16 = 16
 PW_FLAG_FORCE_TILED = 32
+PW_FLAG_FORCE_STRIP = 64
 
 SIZEOF = dict(intpair=8, alnscores=24, alnframe=32, std_alnparams=4, banded_alnparams=12,
               alnprob=32, alnchoice=32, dpcell=16, dptable=32, alignment=24,

@@ -26,7 +26,7 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract
 BKS = (2, 4, 8, 16, 32)
 PACKED_BKS = (4, 8, 12, 16, 20, 24, 28, 32)
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
-HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
+HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
 
 
 def _jobs():
@@ -55,6 +55,9 @@ def _jobs():
     obj = os.path.join(OBJ_DIR, 'pw_trace.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_trace.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_trace.hip')]))
+    obj = os.path.join(OBJ_DIR, 'pw_strip.o')
+    jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_strip.hip'), '-o', obj],
+                 [os.path.join(HERE, 'pw_strip.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_seeds.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-Wno-unused-parameter', '-c', os.path.join(HERE, 'pw_seeds.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_seeds.hip'), os.path.join(ROOT, 'include', 'pw_seeds.h')]))

@@ -49,6 +49,12 @@ hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int n
 hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st);
 hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
+// strip pipeline (pw_strip.h / pw_strip.hip): one standard-mode pair wider than a workgroup
+struct StripParams;
+struct StripTraceParams;
+hipError_t launch_strip_fill(const StripParams& a, bool track, int nworkers, int lds_bytes, hipStream_t st);
+hipError_t launch_strip_trace(const StripTraceParams& p, hipStream_t st);
+hipError_t launch_xcc_census(uint32_t* d_seen8, hipStream_t st);
 hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double* out, hipStream_t st);
 
 }  // namespace pw

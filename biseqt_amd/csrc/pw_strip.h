@@ -1,0 +1,483 @@
+// pw_strip.h -- K2c: ONE pair whose table is wider than a workgroup can hold (standard-mode tables with more than
+// 16 384 diagonals; BASELINE config 3, 100 kb x 100 kb), computed as a PIPELINE OF ROW STRIPS.
+//
+// What it computes: the same cell update as pw_wave.h (reference dptable_solve, biseqt/pwlib/pw.c:47-114, move
+// generators _pw_internals.c:161-299, end-cell search :303-360), cell = (H, 4-bit ordered tie mask).
+//
+// Why another decomposition.  With lanes = DIAGONALS (pw_wave.h) a cell needs its two neighbouring diagonals, so
+// wavefronts that share a band exchange values in BOTH directions every step: inside a workgroup that is an LDS
+// round trip + barrier per step (K2a), across workgroups it forces ghost zones and a kernel boundary every few dozen
+// steps (K2b: 0.37 us per anti-diagonal, 75 ms for config 3).  With lanes = ROWS the dependencies point one way
+// only: cell (x, y) needs (x-1, y), (x-1, y-1) from the row above and (x, y-1) from its own row.  A wavefront owns a
+// strip of 64 consecutive rows and sweeps the columns; lane i works on column y = k - i at step k, takes lane i-1's
+// values of the previous step by ONE DPP wave shift (wave_shr:1) and nothing ever flows back.  The strip below only
+// needs the last row of the strip above, a step behind: a FIFO in memory, written by lane 63 of the producer (one
+// 8-byte granule {2 H + "the D choice is kept", tag} per column) and read by lane 0 of the consumer in chunks of 32
+// columns.  Strips are handed to the resident wavefronts in index order from a work queue, so a strip only ever waits
+// for one that was started before it: no grid barrier, no kernel boundary, no recomputed ghost cells -- the critical
+// path is X + Y steps of ONE cell per lane plus one FIFO hop per strip.
+//
+// Tie masks: lane i packs the 8 cells of 8 consecutive steps into a dword (first cell in the top nibble) and stores
+// 16 bytes per 32 steps; plane layout [strip][step / 32][lane][4] dwords = 0.5 B per cell of the 64-row-aligned table
+// (5.0 GB for config 3, against 10 GB for the bounding parallelogram of the diagonal layout).  strip_walk() is the
+// traceback over this layout: one wavefront per pair, the walk itself runs on wave-uniform (scalar) values and reads
+// the mask words out of a 64-row x 64-step register window with v_readlane.
+//
+// Written against a platform policy P like pw_wave.h, so the CPU lane emulator (tests/emu) runs the same code.
+#ifndef PW_STRIP_H
+#define PW_STRIP_H
+
+#ifndef PW_FN
+#error "PW_FN must be defined by the includer"
+#endif
+
+#include "pw_types.h"
+#include "pw_wave.h"      // U4, PackedU64, pw_first_op
+
+namespace pw {
+
+constexpr int kStripBlock = 32;      // steps per block: one 16-byte mask store per lane, one FIFO chunk
+
+struct StripBest { int32_t score, x, y, have; };
+
+// Uniform parameters of one strip-pipeline launch (one pair).
+struct StripParams {
+  const uint8_t* arena;
+  uint64_t o_off, m_off;
+  uint64_t* fifo;            // [nstrips][fifo_pitch] granules: low dword 2 H + (D kept in that cell) of the strip's last
+                             //   row, high dword the epoch; strip w reads row w - 1
+  uint32_t* masks;           // this pair's plane: [nstrips][nkq][64][4] dwords
+  StripBest* sbest;          // [nstrips] per-strip end-cell candidates
+  uint32_t* ctl;             // [0 .. 7] work-queue heads, one per XCD queue; [kStripAbort] abort flag (a wait ran out of patience)
+  Result* result;            // the pair's record
+  int32_t X, Y;
+  int32_t nstrips, nkq;      // strips of 64 rows; blocks of 32 steps per strip (steps 0 .. Y + 63)
+  int32_t fifo_pitch;        // granules per FIFO row (>= Y + 1)
+  uint32_t epoch;            // tag of this solve: granules of earlier solves never match (the buffer is never cleared)
+  int32_t brule, endrule;
+  int32_t match, mismatch, go, ge;
+  int32_t spin_limit;        // polls of one FIFO chunk before giving up
+  // Placement (speed and store flavour only): strips are dealt in RUNS of run_len consecutive strips; run r is worked
+  // on by the wavefronts of ONE XCD (queue r mod nq), so that a strip and the strip above it normally share an L2 and the
+  // FIFO between them never leaves it (plain stores, L2-served loads).  Only the last strip of a run hands over to another
+  // XCD and writes its row through to memory.  xcc_queue maps the hardware's XCC id to a queue (-1: no such XCD here).
+  int32_t run_len, nq;
+  int32_t xcc_queue[8];
+  uint64_t* stamps;          // tuning aid (PWLIB_STRIP_TRACE): [nstrips][8] clock stamps, or null
+};
+constexpr int kStripAbort = 8;     // index of the abort flag in StripParams::ctl
+
+struct StripTraceParams {
+  const uint32_t* masks;
+  Result* result;
+  uint8_t* tx;               // the pair's transcript slot
+  const int32_t* ends;       // optional explicit end cell (i, j)
+  int32_t X, Y, nkq, tx_cap, gosign;
+};
+
+PW_FN uint64_t strip_mask_index(int nkq, int w, int q, int lane) {      // in dwords
+  return ((uint64_t)((uint64_t)w * nkq + q) * 64 + lane) * 4;
+}
+
+template <class P, bool TRACK>
+struct StripFill {
+  static constexpr int32_t NEG = -(1 << 28);       // "no such predecessor" (pw_wave.h, ScoreTraits<int32_t>)
+  static constexpr int SUB = 8;                    // FIFO granules per hand-off (one store / one load of 8 lanes)
+  const StripParams& a;
+  int lane, w, x;
+  // per lane: the cell computed last (H, what it offers downwards / rightwards), the diagonal predecessor of the
+  // next cell, the row's letter and the mutant letter that travels with the wavefront
+  int32_t Hout, Uout, Lo, Hdiag, best, bestY, hlast, b0, bfirst;
+  uint32_t oc, mc;
+  // lane-0 feeders: lane j holds what lane 0 needs j steps from now (moved down one lane per step)
+  int32_t cH, cU; uint32_t cM;
+  // what lane 63 produced during the last steps, newest in lane 63 (moved down one lane per step) ...
+  int32_t gP;                 // ... as 2 H + "the D choice is kept" (|H| < 2^27)
+  int32_t vmatch, vmis, vge, vgego;   // the scores, held in vector registers (scalar registers are scarce in the loop)
+  uint64_t tE, tO;            // FIFO sub-chunks in flight (lanes 8 .. 15): even / odd sub-chunk numbers
+  uint32_t nM;                // the next block's mutant letters, loaded a block ahead (lanes 0 .. 31)
+  const uint8_t* mseq;
+  uint64_t* fout;             // this strip's FIFO row (written from lane 63's values) or null
+  const uint64_t* fin;        // the FIFO row of the strip above or null
+  bool cross_out;             // the strip below runs on another XCD: write the row through to memory
+  bool cross_in;              // the strip above ran on another XCD: read its row from memory, not from this XCD's L2
+
+  PW_FN explicit StripFill(const StripParams& a_) : a(a_) {}
+  PW_FN void stamp(int i) { if (a.stamps != nullptr && lane == 0) a.stamps[(uint64_t)w * 8 + i] = P::clock(); }
+
+  // MODE 0  steady: every lane holds an in-table cell that is neither the first nor the last of its row
+  //      1  start of a strip (steps 0 .. 63) when its rows are all in the table and the table has more than 64 columns:
+  //         lane i starts at step i; nothing else can happen (this phase is on the critical path of every hop)
+  //      2  anything (ends of rows, rows beyond the table, tiny tables)
+  template <int MODE>
+  PW_FN void step(int k, uint32_t& macc) {
+    constexpr bool RAMP = MODE == 2;
+    // lane 0 takes the feeders' lane-0 values; the feeders then move down a lane (what enters at lane 63 is never used)
+    const int32_t fH = cH, fU = cU; const uint32_t fM = cM;
+    cH = P::shl1(fH, fH); cU = P::shl1(fU, fU); cM = (uint32_t)P::shl1((int32_t)fM, (int32_t)fM);
+    const int32_t Hin = P::shr1(Hout, fH);
+    const int32_t Uin = P::shr1(Uout, fU);
+    mc = (uint32_t)P::shr1((int32_t)mc, (int32_t)fM);
+    const int y = k - lane;
+    const int32_t hD = Uin, hI = Lo;
+    const int32_t hM = Hdiag + (oc == mc ? vmatch : vmis);
+    bool active = true;
+    int32_t bq = b0;
+    if (RAMP) {
+      active = y >= 0 && y <= a.Y && x <= a.X;
+      const bool edge = x == 0 || y == 0, orig = x == 0 && y == 0;
+      const bool ball = a.brule == BRULE_ANY || (edge && (a.brule == BRULE_EDGE || orig));
+      bq = ball ? 0 : NEG;
+    } else if (MODE == 1) {
+      active = y >= 0;
+      // the first cell of a row may begin an alignment on the table edge (b0 already covers "anywhere" and row 0)
+      bq = y == 0 ? bfirst : b0;
+    }
+    // maximum in the reference's candidate order B, D, I, M (pw.c:92-103); every kept choice shares the score
+    int32_t Hn = hD > hI ? hD : hI;
+    Hn = hM > Hn ? hM : Hn;
+    Hn = bq > Hn ? bq : Hn;
+    const bool bB = Hn == bq, bD = hD == Hn, bI = hI == Hn;
+    // offers to the cell below / to the right (_alnchoice_ID, _pw_internals.c:268-278; go <= 0 here)
+    const int32_t Un = Hn + (bD ? vge : vgego), Ln = Hn + (bI ? vge : vgego);
+    // the M bit stays 0: with go <= 0 the walker never looks at it (the first kept op is M exactly when none of
+    // B, D, I is kept: pw_first_op)
+    const uint32_t nib = (bB ? (uint32_t)MB : 0u) | (bD ? (uint32_t)MD : 0u) | (bI ? (uint32_t)MI : 0u);
+    Hdiag = Hin;
+    if (RAMP) {
+      macc = (macc << 4) | (active ? nib : 0u);
+      Hout = active ? Hn : Hout; Uout = active ? Un : Uout; Lo = active ? Ln : Lo;
+      if (active && y == a.Y) hlast = Hn;
+      if (TRACK) {
+        const bool upd = active && Hn > best;
+        best = upd ? Hn : best; bestY = upd ? y : bestY;
+      }
+    } else if (MODE == 1) {
+      macc = (macc << 4) | nib;                    // (cells before a row's start are never visited by the walker)
+      Hout = active ? Hn : Hout; Uout = active ? Un : Uout; Lo = active ? Ln : Lo;
+      if (TRACK) {
+        const bool upd = active && Hn > best;
+        best = upd ? Hn : best; bestY = upd ? y : bestY;
+      }
+    } else {
+      macc = (macc << 4) | nib;
+      Hout = Hn; Uout = Un; Lo = Ln;
+      if (TRACK) {
+        const bool upd = Hn > best;
+        best = upd ? Hn : best; bestY = upd ? y : bestY;
+      }
+    }
+    // what the strip below will read: lane 63's cells, collected across the lanes (lane 63 has no source and keeps
+    // its own new value; a cell outside the table is dropped when the granules are written)
+    gP = P::shl1(gP, Hn + Hn + (bD ? 1 : 0));
+  }
+
+  // After the 8 steps k0 .. k0 + 7: lane 56 + j holds lane 63's cell of step k0 + j, column y = k0 + j - 63.
+  PW_FN void flush_out(int k0) {
+    if (fout == nullptr) return;
+    const int y = k0 + (lane - 56) - 63;
+    if (lane >= 56 && y >= 0 && y <= a.Y) {
+      const uint64_t g = ((uint64_t)a.epoch << 32) | (uint64_t)(uint32_t)gP;
+      if (cross_out) P::fifo_store(fout + y, g);
+      else P::fifo_store_local(fout + y, g);
+    }
+  }
+
+  // FIFO sub-chunk S = columns 8 S .. 8 S + 7 of the row above, one granule per lane `first` .. `first` + 7
+  PW_FN uint64_t load_sub(int S, int first) const {
+    const int e = SUB * S + lane - first;
+    if (!(lane >= first && lane < first + SUB && e <= a.Y)) return 0;
+    return cross_in ? P::fifo_load(fin + e) : P::fifo_load_local(fin + e);
+  }
+  // Waits until the granules of sub-chunk S (in `t`, lanes first ..) carry this solve's tag and puts them into the
+  // feeders of those lanes.  False if the wait was abandoned.
+  PW_FN bool merge_sub(uint64_t t, int S, int first) {
+    const int e = SUB * S + lane - first;
+    const bool mine = lane >= first && lane < first + SUB;
+    const bool need = mine && e <= a.Y;
+    int spins = 0;
+    while (!P::all(!need || (uint32_t)(t >> 32) == a.epoch)) {
+      if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
+        P::flag_set(a.ctl + kStripAbort);
+        return false;
+      }
+      P::sleep();
+      if (need) t = P::fifo_poll(fin + e);
+    }
+    const int32_t pk = (int32_t)(uint32_t)t;
+    const int32_t h = need ? (pk >> 1) : NEG;
+    const int32_t u = need ? h + ((pk & 1) ? a.ge : a.ge + a.go) : NEG;
+    cH = mine ? h : cH; cU = mine ? u : cU;
+    return true;
+  }
+  PW_FN uint32_t load_letters(int q) const {        // m[k - 1] for the steps k = 32 q + lane of block q
+    const int e = kStripBlock * q + lane;
+    const int mi = e - 1 < 0 ? 0 : (e - 1 > a.Y - 1 ? (a.Y > 0 ? a.Y - 1 : 0) : e - 1);
+    return lane < kStripBlock ? (uint32_t)mseq[mi] : 0u;
+  }
+
+  // The 8 steps of sub-chunk J of block q: first the hand-over of the FIFO data that lane 0 will need 8 steps from now
+  // (loaded 16 steps ago; the load for 16 steps further on is issued right away), then the steps, then what lane 63
+  // produced goes out.
+  template <int MODE, int J>
+  PW_FN bool sub_block(int q, uint32_t& m) {
+    const int S = 4 * q + J;
+    const int k0 = kStripBlock * q + SUB * J;
+    if (fin != nullptr) {
+      if (J & 1) { if (!merge_sub(tE, S + 1, SUB)) return false; tE = load_sub(S + 3, SUB); }
+      else { if (!merge_sub(tO, S + 1, SUB)) return false; tO = load_sub(S + 3, SUB); }
+    }
+    // what lane 63 produced during the previous 8 steps goes out here, BEHIND the hand-over above: the compiler waits for
+    // vmcnt(0) wherever a load result is used while a store is in flight (loads and stores share the counter), so the
+    // only memory operations in flight at that wait should be ones issued 8 steps earlier
+    flush_out(k0 - SUB);
+    m = 0;
+    if (MODE == 2) {
+#pragma unroll 1
+      for (int s = 0; s < SUB; s++) step<2>(k0 + s, m);
+    } else {
+#pragma unroll
+      for (int s = 0; s < SUB; s++) step<MODE>(k0 + s, m);
+    }
+    return true;
+  }
+  template <int MODE>
+  PW_FN bool block(int q) {
+    cM = nM;
+    nM = load_letters(q + 1);
+    uint32_t mw[4];
+    if (!sub_block<MODE, 0>(q, mw[0])) return false;
+    if (!sub_block<MODE, 1>(q, mw[1])) return false;
+    if (!sub_block<MODE, 2>(q, mw[2])) return false;
+    if (!sub_block<MODE, 3>(q, mw[3])) return false;
+    U4 v; v.x = mw[0]; v.y = mw[1]; v.z = mw[2]; v.w = mw[3];
+    *(U4*)(a.masks + strip_mask_index(a.nkq, w, q, lane)) = v;
+    return true;
+  }
+
+  PW_FN bool run(int w_, bool cross_in_, bool cross_out_) {
+    lane = P::lane();
+    w = w_;
+    cross_in = cross_in_; cross_out = cross_out_;
+    x = 64 * w + lane;
+    const uint8_t* oseq = a.arena + a.o_off;
+    mseq = a.arena + a.m_off;
+    const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
+    oc = (uint32_t)oseq[oi];
+    mc = 0;
+    Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
+    gP = 0; cH = NEG; cU = NEG; cM = 0; tE = 0; tO = 0;
+    vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
+    // steady blocks hold no first-row / first-column cell except row 0 itself
+    b0 = (a.brule == BRULE_ANY || (a.brule == BRULE_EDGE && x == 0)) ? 0 : NEG;
+    // ... and the first cell of a row (y == 0): the table edge, or the origin for row 0
+    bfirst = (a.brule == BRULE_ANY || a.brule == BRULE_EDGE || x == 0) ? 0 : NEG;
+    fin = w > 0 ? a.fifo + (uint64_t)(w - 1) * (uint64_t)a.fifo_pitch : nullptr;
+    fout = w + 1 < a.nstrips ? a.fifo + (uint64_t)w * (uint64_t)a.fifo_pitch : nullptr;
+    nM = load_letters(0);
+    stamp(1);
+    if (fin != nullptr) {
+      // sub-chunks 0 and 1 in ONE poll (lanes 0 .. 15, granule = lane): 0 goes straight into the feeders, 1 already sits in
+      // the lanes the first hand-over takes it from, 2 is put in flight
+      const bool need = lane < 2 * SUB && lane <= a.Y;
+      uint64_t t = need ? P::fifo_load(fin + lane) : 0;
+      int spins = 0;
+      while (!P::all(!need || (uint32_t)(t >> 32) == a.epoch)) {
+        if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
+          P::flag_set(a.ctl + kStripAbort);
+          return false;
+        }
+        P::sleep();
+        if (need) t = P::fifo_poll(fin + lane);
+      }
+      if (!merge_sub(t, 0, 0)) return false;
+      tO = t; tE = load_sub(2, SUB);
+    }
+    stamp(2);
+    for (int q = 0; q < a.nkq; q++) {
+      const int k0 = kStripBlock * q;
+      if (q == 2) stamp(3);
+      if (q == 3) stamp(4);
+      // steady: every lane holds an in-table cell on every step of the block and none its first or last one
+      const bool steady = k0 >= 63 && k0 + kStripBlock - 1 < a.Y;
+      const bool starting = k0 < 64 && a.Y > 64 && 64 * w + 63 <= a.X;
+      if (steady) { if (!block<0>(q)) return false; }
+      else if (starting) { if (!block<1>(q)) return false; }
+      else { if (!block<2>(q)) return false; }
+    }
+    flush_out(kStripBlock * a.nkq - SUB);      // the last 8 steps' cells (columns <= Y only)
+    stamp(5);
+    finish();
+    return true;
+  }
+
+  // The strip's candidate for the end cell: (score desc, scan rank asc) over its rows (_std_find_optimal,
+  // _pw_internals.c:303-360).
+  PW_FN static uint64_t rank_of(int endrule, int X, int Y, int cx, int cy) {
+    if (endrule == END_CORNER) return 0;
+    if (endrule == END_STD_OVERLAP) return cx < X ? (uint64_t)(uint32_t)cx : (uint64_t)(uint32_t)(X + cy);
+    return (uint64_t)(uint32_t)cx * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)cy;
+  }
+  PW_FN void finish() {
+    const int endrule = a.endrule;
+    int32_t cs = NEG; int cx = x, cy = a.Y; bool have = false;
+    if (x <= a.X) {
+      if (endrule == END_CORNER) { have = x == a.X; cs = hlast; }
+      else if (endrule == END_STD_OVERLAP) {
+        // last column (x < X): cell (x, Y); last row: its first best cell
+        if (x < a.X) { have = true; cs = hlast; }
+        else { have = true; cs = best; cy = bestY; }
+      } else { have = true; cs = best; cy = bestY; }
+    }
+    uint64_t ck = rank_of(endrule, a.X, a.Y, cx, cy);
+    int hv = have ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const int32_t os = P::shfl_xor(cs, off);
+      const uint32_t klo = (uint32_t)P::shfl_xor((int32_t)(uint32_t)ck, off), khi = (uint32_t)P::shfl_xor((int32_t)(uint32_t)(ck >> 32), off);
+      const uint64_t ok_ = ((uint64_t)khi << 32) | klo;
+      const int ox = P::shfl_xor(cx, off), oy = P::shfl_xor(cy, off), oh = P::shfl_xor(hv, off);
+      const bool take = oh && (!hv || os > cs || (os == cs && ok_ < ck));
+      if (take) { cs = os; ck = ok_; cx = ox; cy = oy; hv = 1; }
+    }
+    if (lane == 0) {
+      StripBest sb; sb.score = cs; sb.x = cx; sb.y = cy; sb.have = hv;
+      a.sbest[w] = sb;
+    }
+  }
+};
+
+// After every strip has finished: the pair's end cell from the per-strip candidates (one wavefront).
+template <class P>
+PW_FN void strip_reduce(const StripParams& a) {
+  const int lane = P::lane();
+  int32_t cs = -(1 << 28); uint64_t ck = ~(uint64_t)0; int cx = -1, cy = -1, hv = 0;
+  for (int w = lane; w < a.nstrips; w += 64) {
+    const StripBest sb = a.sbest[w];
+    if (!sb.have) continue;
+    const uint64_t k = StripFill<P, true>::rank_of(a.endrule, a.X, a.Y, sb.x, sb.y);
+    if (!hv || sb.score > cs || (sb.score == cs && k < ck)) { cs = sb.score; ck = k; cx = sb.x; cy = sb.y; hv = 1; }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int32_t os = P::shfl_xor(cs, off);
+    const uint32_t klo = (uint32_t)P::shfl_xor((int32_t)(uint32_t)ck, off), khi = (uint32_t)P::shfl_xor((int32_t)(uint32_t)(ck >> 32), off);
+    const uint64_t ok_ = ((uint64_t)khi << 32) | klo;
+    const int ox = P::shfl_xor(cx, off), oy = P::shfl_xor(cy, off), oh = P::shfl_xor(hv, off);
+    const bool take = oh && (!hv || os > cs || (os == cs && ok_ < ck));
+    if (take) { cs = os; ck = ok_; cx = ox; cy = oy; hv = 1; }
+  }
+  if (lane == 0) {
+    Result r;
+    r.score = (double)cs; r.opt_i = cx; r.opt_j = cy;          // standard mode: table coordinates are (x, y)
+    r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;
+    // LOCAL / START_ANCHORED start from the score of cell (0,0), i.e. 0 (_pw_internals.c:342)
+    if (!hv || (a.endrule == END_STD_LOCAL && !(cs > 0))) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; }
+    if (P::flag_load(a.ctl + kStripAbort) != 0u) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; r.status = ST_BADPATH; }
+    *a.result = r;
+  }
+}
+
+// ---- traceback over the strip layout: one wavefront per pair ------------------------------------------------------
+// A walk is a chain of dependent steps, but in an alignment of similar sequences nine steps out of ten continue a
+// run of diagonal moves, and a run can be taken in ONE step: the wave keeps a window of the mask plane on chip (LDS:
+// all 64 rows of the current strip x 128 steps = 4 KB), lane j looks at the cell j moves up the diagonal from the
+// current one, a ballot finds how many of them in a row are "pure M" (none of B, D, I kept: the first kept op is M
+// whatever led here), and the whole run is written with one store instruction.  Only the cells that break a run go
+// through the scalar predecessor rule (pw_wave.h, trace_walk).  The next window (further down this strip, or the strip
+// above, whichever the diagonal reaches first) is loaded while the current one is being walked.
+constexpr int kWalkGroups = 4;                        // 32-step groups per window
+constexpr int kWalkWinWords = kWalkGroups * 64 * 4;   // dwords of LDS
+
+template <class P>
+PW_FN void strip_walk(const StripTraceParams& p, uint32_t* win) {
+  const int lane = P::lane();
+  Result r = *p.result;
+  if (r.status & ST_BADPATH) return;
+  const int ei = P::uniform(p.ends ? p.ends[0] : r.opt_i), ej = P::uniform(p.ends ? p.ends[1] : r.opt_j);
+  if (ei < 0 || ej < 0) {
+    if (lane == 0) { r.tx_len = 0; r.status = 0; *p.result = r; }
+    return;
+  }
+  const int gosign = p.gosign, nkq = p.nkq;
+  int x = ei, y = ej;
+  int pos = p.tx_cap, nms = 0, bad = 0, prev = 3;
+  uint8_t* tx = p.tx;
+  int cw = -1, cg = -1;                 // the window: strip cw, groups cg - 3 .. cg
+  int pw = -1, pg = -1;                 // the window being loaded ahead
+  U4 pre[kWalkGroups];
+#pragma unroll
+  for (int q = 0; q < kWalkGroups; q++) { pre[q].x = pre[q].y = pre[q].z = pre[q].w = 0; }
+  while (true) {
+    if (x < 0 || y < 0 || x > p.X || y > p.Y) { bad = 1; break; }
+    const int w = x >> 6, i = x & 63, k = y + i, g = k >> 5;
+    if (w != cw || g > cg || g < cg - (kWalkGroups - 1)) {
+      // ---- new window.  Use the one loaded ahead if it holds the cell with at least two groups below it.
+      const bool hit = w == pw && g <= pg && g >= pg - (kWalkGroups - 3);
+      cw = w; cg = hit ? pg : g;
+      P::wave_sync();
+#pragma unroll
+      for (int q = 0; q < kWalkGroups; q++) {
+        U4 v = pre[q];
+        if (!hit) {
+          v.x = v.y = v.z = v.w = 0;
+          if (cg - q >= 0) v = *(const U4*)(p.masks + strip_mask_index(nkq, cw, cg - q, lane));
+        }
+        uint32_t* dst = win + (q * 64 + lane) * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+      P::wave_sync();
+      // ---- load ahead: the diagonal through the cell leaves the window at the top of the strip or at the window's
+      //      lowest step, whichever comes first
+      const int i2 = x & 63, k2 = y + i2;
+      const int mi = i2 + 1, mk = ((k2 - 32 * (cg - (kWalkGroups - 1))) >> 1) + 1;
+      if (mi <= mk && cw > 0 && y - mi >= 0) { pw = cw - 1; pg = (y - mi + 63) >> 5; }
+      else { pw = cw; pg = cg - kWalkGroups; }
+#pragma unroll
+      for (int q = 0; q < kWalkGroups; q++) {
+        pre[q].x = pre[q].y = pre[q].z = pre[q].w = 0;
+        if (pg - q >= 0) pre[q] = *(const U4*)(p.masks + strip_mask_index(nkq, pw, pg - q, lane));
+      }
+      if (pg < 0) pw = -1;
+    }
+    // ---- lane j looks at the cell j diagonal moves up from (x, y)
+    const int ij = i - lane, kj = k - 2 * lane;
+    const bool inwin = ij >= 0 && y - lane >= 0 && kj >= 32 * (cg - (kWalkGroups - 1));
+    uint32_t nibj = 0xfu;
+    if (inwin) {
+      const uint32_t word = win[((cg - (kj >> 5)) * 64 + ij) * 4 + ((kj >> 3) & 3)];
+      nibj = (word >> (4 * (7 - (kj & 7)))) & 15u;
+    }
+    const uint64_t pure = P::ballot(inwin && (nibj & 7u) == 0u);
+    int run = (int)__builtin_ctzll(~pure | ((uint64_t)1 << 63));   // pure-M cells in a row, starting with this one
+    const int lim = x < y ? x : y;                                  // a diagonal move needs x >= 1 and y >= 1
+    run = run < lim ? run : lim;
+    run = run < pos ? run : pos;
+    if (run > 0) {
+      if (lane < run) tx[pos - 1 - lane] = (uint8_t)'X';
+      pos -= run; nms += run; x -= run; y -= run; prev = 3;
+      continue;
+    }
+    // ---- the current cell breaks the run: the predecessor rule on its mask
+    const uint32_t pm = P::readlane(nibj, 0);
+    int op;
+    if (prev == 3 || gosign == 0) op = pw_first_op(pm);
+    else if (gosign < 0) op = (pm & (1u << prev)) ? prev : pw_first_op(pm);
+    else { const uint32_t others = pm & ~(1u << prev); op = others ? pw_first_op(others) : prev; }
+    if (op == 0 || pos <= 0) break;
+    if (lane == 0) tx[pos - 1] = (uint8_t)(op == 3 ? 'X' : (op == 1 ? 'D' : 'I'));
+    pos -= 1;
+    nms += (op == 3);
+    x -= (op != 2); y -= (op != 1);
+    prev = op;
+  }
+  if (lane == 0) {
+    r.origin_idx = x; r.mutant_idx = y;
+    r.tx_len = p.tx_cap - pos;
+    r.status = ST_TRACED | (r.tx_len == 0 ? ST_EMPTY : 0) | ((x + y + nms <= 0) ? ST_PANICK : 0) | (bad ? ST_BADPATH : 0);
+    *p.result = r;
+  }
+}
+
+}  // namespace pw
+#endif

@@ -1,0 +1,125 @@
+// pw_strip.hip -- gfx950 kernels of the strip pipeline (pw_strip.h, K2c): one pair wider than a workgroup.
+//
+//   k_fill_strip<TRACK>   persistent wavefronts (one per workgroup) draw strips of 64 rows from a work queue in index
+//                         order; a strip takes the row above it from a FIFO in memory (8-byte granules written and read
+//                         with agent-scope relaxed atomics: `global_store/load_dwordx2 ... sc1`, the data-tagged
+//                         hand-off of MI355X_MICROARCH.md -- no fence, no flag) and everything else from its own lanes
+//                         by DPP wave shifts.  Every wait is bounded: a wave that waits too long raises the abort flag
+//                         and every wave leaves at its next look at it, so the grid always drains.
+//   k_strip_finish        end cell of the pair from the per-strip candidates.
+//   k_trace_strip         traceback over the strip layout, one wavefront per pair.
+#include "pw_device.h"
+#include "pw_strip.h"
+
+namespace pw {
+
+struct DevPS {
+  PW_FN static int lane() { return (int)(threadIdx.x & 63u); }
+  PW_FN static int32_t shr1(int32_t v, int32_t old) {
+    return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+  }
+  PW_FN static int32_t shl1(int32_t v, int32_t old) {
+    return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  }
+  PW_FN static int32_t shfl_xor(int32_t v, int m) { return __shfl_xor(v, m, 64); }
+  PW_FN static int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+  PW_FN static bool all(bool p) { return __all(p ? 1 : 0) != 0; }
+  PW_FN static uint64_t ballot(bool p) { return __ballot(p ? 1 : 0); }
+  PW_FN static void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  PW_FN static uint32_t readlane(uint32_t v, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)v, i); }
+  // FIFO granules: 8-byte agent-scope relaxed atomics on GLOBAL addresses (global_load/store_dwordx2 ... sc1; a generic
+  // pointer would make these flat_* operations, which complete out of order and force vmcnt(0) waits on everything)
+  typedef __attribute__((address_space(1))) uint64_t g_u64;
+  typedef __attribute__((address_space(1))) uint32_t g_u32;
+  PW_FN static uint64_t fifo_load(const uint64_t* p) {
+    return __hip_atomic_load((const g_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  PW_FN static void fifo_store(uint64_t* p, uint64_t v) {
+    __hip_atomic_store((g_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // inside one XCD: a plain store stays in the shared L2, where the reader's L1-bypassing load finds it
+  // ... with a load that bypasses the L1 and is served by that L2 (`nt`)
+  PW_FN static uint64_t fifo_load_local(const uint64_t* p) { return __builtin_nontemporal_load((const g_u64*)p); }
+  // (NOT volatile: a volatile store is emitted write-through and followed by s_waitcnt vmcnt(0))
+  PW_FN static void fifo_store_local(uint64_t* p, uint64_t v) { *(g_u64*)p = v; }
+  // Loads of the waiting loops: issued and waited for inside one asm statement, so that the compiler's count of
+  // outstanding memory operations -- which lets the fast path wait for exactly the load it needs (vmcnt(N)) -- never
+  // meets a load inside a loop of unknown length (that would turn every wait into vmcnt(0)).
+  PW_FN static uint64_t fifo_poll(const uint64_t* p) {
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  }
+  PW_FN static uint32_t flag_poll(const uint32_t* p) {
+    uint32_t v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  }
+  PW_FN static void sleep() { __builtin_amdgcn_s_sleep(1); }
+  PW_FN static uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }      // 100 MHz
+  PW_FN static uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load((const g_u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  PW_FN static void flag_set(uint32_t* p) { __hip_atomic_store((g_u32*)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  PW_FN static int32_t in_vgpr(int32_t v) { asm volatile("" : "+v"(v)); return v; }
+};
+
+// XCC id of the executing wavefront (HW_REG_XCC_ID = 20, bits 3:0).  Used for placement, which decides speed and the
+// flavour of a store, never whether a strip gets done: a queue nobody serves ends in the bounded waits' abort.
+PW_FN int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu); }
+
+template <bool TRACK>
+__global__ __launch_bounds__(64) void k_fill_strip(const StripParams a) {
+  const int qi = a.xcc_queue[xcc_id() & 7];
+  if (qi < 0) return;
+  for (;;) {
+    int t = 0;
+    if (threadIdx.x == 0) t = (int)atomicAdd(a.ctl + qi, 1u);     // this XCD's strips, in index order
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int run = qi + a.nq * (t / a.run_len), i = t % a.run_len;
+    const int w = run * a.run_len + i;
+    if (w >= a.nstrips) return;
+    if (DevPS::flag_load(a.ctl + kStripAbort) != 0u) return;
+    if (a.stamps != nullptr && threadIdx.x == 0) {
+      a.stamps[(uint64_t)w * 8] = DevPS::clock();
+      a.stamps[(uint64_t)w * 8 + 7] = (uint64_t)xcc_id() | ((uint64_t)blockIdx.x << 8);
+    }
+    StripFill<DevPS, TRACK> f(a);
+    if (!f.run(w, i == 0, i == a.run_len - 1)) return;
+  }
+}
+
+// Which XCC ids does this device have?  (One workgroup per slot of a grid large enough to reach every XCD.)
+__global__ __launch_bounds__(64) void k_xcc_census(uint32_t* seen) {
+  if (threadIdx.x == 0) atomicOr(seen + (xcc_id() & 7), 1u);
+}
+
+__global__ __launch_bounds__(64) void k_strip_finish(const StripParams a) { strip_reduce<DevPS>(a); }
+
+__global__ __launch_bounds__(64) void k_trace_strip(const StripTraceParams p) {
+  __shared__ uint32_t win[kWalkWinWords];
+  strip_walk<DevPS>(p, win);
+}
+
+hipError_t launch_strip_fill(const StripParams& a, bool track, int nworkers, int lds_bytes, hipStream_t st) {
+  // the work queue head and the abort flag start at zero
+  hipError_t e = hipMemsetAsync(a.ctl, 0, 16 * sizeof(uint32_t), st);
+  if (e != hipSuccess) return e;
+  const dim3 grid((unsigned)nworkers), block(64);
+  if (track) hipLaunchKernelGGL((k_fill_strip<true>), grid, block, (size_t)lds_bytes, st, a);
+  else hipLaunchKernelGGL((k_fill_strip<false>), grid, block, (size_t)lds_bytes, st, a);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_strip_finish, dim3(1), dim3(64), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_xcc_census(uint32_t* d_seen8, hipStream_t st) {
+  hipLaunchKernelGGL(k_xcc_census, dim3(4096), dim3(64), 0, st, d_seen8);
+  return hipGetLastError();
+}
+
+hipError_t launch_strip_trace(const StripTraceParams& p, hipStream_t st) {
+  hipLaunchKernelGGL(k_trace_strip, dim3(1), dim3(64), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace pw

@@ -53,7 +53,7 @@ struct PairDesc {
   int32_t bk;          // diagonals per lane of the fill kernel that owns this pair (mask plane layout)
   int32_t solvable;    // 0: dptable_init fails for this pair (or its table is empty); kernels skip it
   int32_t nl;          // lanes that hold this pair = row length of its mask plane (64 unless lane-packed)
-  int32_t pad_;
+  int32_t layout;      // mask plane layout: 0 diagonal-major (mask_word_index), 1 row strips (pw_strip.h)
 };                     // 96 bytes
 
 // One wavefront of the lane-packed fill kernel: `count` pairs side by side, `nl` lanes each.

@@ -766,9 +766,9 @@ struct WaveFill16 {
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
     // unroll depth: full for narrow lanes (the letter-window shifts become register renames), shallower for
     // wide ones, where the live state already fills the register file
-#pragma unroll(UNR)
+#pragma clang loop unroll_count(UNR)
     for (int k = 0; k < 4; k++) iteration16<EDGE, 0>(8 * b + k, k);
-#pragma unroll(UNR)
+#pragma clang loop unroll_count(UNR)
     for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
     // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept).
     // Slots are gathered into their natural order so that every group of 4 goes out as one 16-byte store.
@@ -978,7 +978,7 @@ PW_FN void trace_walk(const TraceParams& p, int pair, uint32_t* win /* WIN_WORDS
   // everything the loops need is copied into locals first: the byte stores of the ops go through a
   // uint8_t*, which the compiler must assume aliases the descriptors
   const PairDesc pdv = p.pairs[pair];
-  if (!pdv.solvable) return;
+  if (!pdv.solvable || pdv.layout != 0) return;      // (strip-layout pairs have their own walker: pw_strip.h)
   Result r = p.results[pair];
   const int ei = p.ends ? p.ends[2 * pair] : r.opt_i;
   const int ej = p.ends ? p.ends[2 * pair + 1] : r.opt_j;

@@ -20,6 +20,9 @@
 #include "../../include/pw_batch.h"
 #include "pw_launch.h"
 #include "pw_plan.h"
+#define PW_FN inline
+#include "pw_strip.h"
+#include <atomic>
 
 extern "C" {
 #include "../../include/pwlib.h"
@@ -152,6 +155,10 @@ struct pw_batch {
   std::vector<pw::PairDesc> descs;
   std::vector<BkClass> classes;
   std::vector<pw::WaveDesc> waves;      // lane-packed kernel: one per wavefront
+  std::vector<int32_t> strips;          // standard-mode pairs wider than a workgroup: the strip pipeline (K2c, pw_strip.h)
+  uint64_t* d_fifo = nullptr; size_t fifo_alloc = 0, fifo_bytes = 0;   // FIFO rows of the largest strip pair (pairs run one after another)
+  pw::StripBest* d_sbest = nullptr;      // [max strips]
+  uint32_t* d_ctl = nullptr;             // [strip pairs][2]: work queue head, abort flag
   std::vector<int32_t> tiled;           // pairs that go through the time-blocked tiled kernel (K2b)
   void* d_state[2] = {nullptr, nullptr}; // their per-diagonal state, double buffered (shared: pairs run one after another)
   int32_t st_pitch = 0;
@@ -189,6 +196,9 @@ int batch_free_device(pw_batch* b) {
   if (b->d_subst) (void)hipFree(b->d_subst);
   if (b->d_ends) (void)hipFree(b->d_ends);
   if (b->d_waves) (void)hipFree(b->d_waves);
+  pool_give(b->device, b->d_fifo, b->fifo_alloc);
+  if (b->d_sbest) (void)hipFree(b->d_sbest);
+  if (b->d_ctl) (void)hipFree(b->d_ctl);
   if (b->d_state[0]) (void)hipFree(b->d_state[0]);
   if (b->d_state[1]) (void)hipFree(b->d_state[1]);
   if (b->ev_fill0) (void)hipEventDestroy(b->ev_fill0);
@@ -285,7 +295,7 @@ int batch_build(pw_batch* b) {
     pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && maxnd <= 64 * 20 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
   }
   if (prule >= 0 && pfits && !b->use_f64 &&
-      !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED)) && maxnd <= 2048 &&
+      !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd <= 2048 &&
       nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0) {
     // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
     // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
@@ -318,6 +328,19 @@ int batch_build(pw_batch* b) {
     if (!d.solvable) continue;
     int bk, nl, nw = 1;
     bool tiled = false;
+    const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
+                          !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED)) && !env_int("PWLIB_NO_STRIP", 0);
+    if (strip_ok && ((b->flags & PW_FLAG_FORCE_STRIP) || d.ndiag > 2048 * pw::kMaxWavesPerPair)) {
+      // one pair wider than a workgroup, integer scores, simple scoring: rows in strips of 64, a pipeline of wavefronts
+      const int nstrips = (d.X + 1 + 63) / 64, nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
+      d.layout = 1; d.bk = 0; d.nl = 64;
+      d.mask_off = mask_words;
+      mask_words += (uint64_t)nstrips * nkq * 64 * 4;
+      d.h_off = h_elems;
+      b->strips.push_back(k);
+      b->fifo_bytes = std::max<size_t>(b->fifo_bytes, (size_t)nstrips * (size_t)((d.Y + 1 + 63) / 64 * 64) * 8);
+      continue;
+    }
     if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
     else if ((b->flags & PW_FLAG_FORCE_TILED) || d.ndiag > 2048 * pw::kMaxWavesPerPair) {
       // wider than a workgroup holds (or forced): time-blocked tiles of the band, one pair after another
@@ -401,6 +424,15 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipMemcpy(b->d_subst, si.data(), 4 * si.size(), hipMemcpyHostToDevice));
   }
   if (b->n) HIP_TRY(hipMemcpy(b->d_pairs, b->descs.data(), sizeof(pw::PairDesc) * b->n, hipMemcpyHostToDevice));
+  if (!b->strips.empty()) {
+    int maxs = 0;
+    for (int32_t k : b->strips) maxs = std::max(maxs, (b->descs[k].X + 1 + 63) / 64);
+    HIP_TRY(pool_alloc(b->device, (void**)&b->d_fifo, b->fifo_bytes, &b->fifo_alloc));
+    // granules are recognised by their epoch tag: whatever the (possibly recycled) buffer holds must never look like one
+    HIP_TRY(hipMemset(b->d_fifo, 0, b->fifo_bytes));
+    HIP_TRY(hipMalloc((void**)&b->d_sbest, sizeof(pw::StripBest) * (size_t)maxs));
+    HIP_TRY(hipMalloc((void**)&b->d_ctl, 64 * b->strips.size()));
+  }
   if (!b->tiled.empty()) {
     HIP_TRY(hipMalloc(&b->d_state[0], (size_t)5 * b->st_pitch * 8));
     HIP_TRY(hipMalloc(&b->d_state[1], (size_t)5 * b->st_pitch * 8));
@@ -423,6 +455,78 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipEventCreate(&b->ev_tr0)); HIP_TRY(hipEventCreate(&b->ev_tr1));
   }
   if (tim && b->n > 1000) fprintf(stderr, "pwlib timing: batch of %d pairs: planning %.1f ms, device buffers + descriptors %.1f ms\n", b->n, t_plan - t_build0, tnow() - t_plan);
+  return 0;
+}
+
+std::atomic<uint32_t> g_strip_epoch{1};
+
+// XCC ids present on a device (the strip pipeline keeps runs of consecutive strips on one XCD): counted once per device
+// by a census kernel.  xcc_queue[id] = queue index or -1; returns the number of queues (0 on error).
+int xcc_queues(int device, int32_t* xcc_queue) {
+  static std::mutex mu;
+  static int cached_n[kMaxDevices] = {0};
+  static int32_t cached_map[kMaxDevices][8];
+  std::lock_guard<std::mutex> lk(mu);
+  if (device < 0 || device >= kMaxDevices) return 0;
+  if (cached_n[device] == 0) {
+    uint32_t* d = nullptr; uint32_t h[8] = {0};
+    if (hipMalloc((void**)&d, sizeof h) != hipSuccess) return 0;
+    bool ok = hipMemset(d, 0, sizeof h) == hipSuccess && pw::launch_xcc_census(d, nullptr) == hipSuccess &&
+              hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return 0;
+    int n = 0;
+    for (int i = 0; i < 8; i++) cached_map[device][i] = h[i] ? n++ : -1;
+    cached_n[device] = n;
+  }
+  memcpy(xcc_queue, cached_map[device], sizeof cached_map[device]);
+  return cached_n[device];
+}
+
+// K2c: the strip pairs of a batch, one after another (each one fills the chip by itself)
+int launch_strip_fills(pw_batch* b, hipStream_t st) {
+  static const int workers = std::max(1, env_int("PWLIB_STRIP_WAVES", 1024));
+  static const int lds_kb = std::max(0, env_int("PWLIB_STRIP_LDS_KB", 0));
+  size_t q = 0;
+  for (int32_t k : b->strips) {
+    const pw::PairDesc& d = b->descs[k];
+    pw::StripParams a;
+    memset(&a, 0, sizeof a);
+    a.arena = b->d_arena; a.o_off = d.o_off; a.m_off = d.m_off;
+    a.fifo = b->d_fifo; a.masks = b->d_masks + d.mask_off; a.sbest = b->d_sbest; a.ctl = b->d_ctl + 16 * q++;
+    a.result = b->d_results + k;
+    a.X = d.X; a.Y = d.Y;
+    a.nstrips = (d.X + 1 + 63) / 64; a.nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
+    a.fifo_pitch = (d.Y + 1 + 63) / 64 * 64;
+    uint32_t e = g_strip_epoch.fetch_add(1);
+    if (e == 0) e = g_strip_epoch.fetch_add(1);
+    a.epoch = e;
+    a.brule = b->brule; a.endrule = b->endrule;
+    a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
+    a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
+    a.spin_limit = env_int("PWLIB_STRIP_SPIN_LIMIT", 1 << 21);
+    a.nq = xcc_queues(b->device, a.xcc_queue);
+    if (a.nq <= 0) return fail("could not determine the XCDs of the device");
+    a.run_len = std::max(1, env_int("PWLIB_STRIP_RUN", std::max(1, workers / a.nq)));
+    const bool track = b->endrule != pw::END_CORNER;
+    // tuning aid: PWLIB_STRIP_TRACE=<file> dumps per-strip clock stamps (100 MHz) of the first strip pair: dequeue, set-up
+    // done, first granules seen, steps 64 / 96 reached, end; [7] = XCC id | workgroup << 8
+    const char* trace = getenv("PWLIB_STRIP_TRACE");
+    uint64_t* d_stamps = nullptr;
+    if (trace && *trace && q == 1) {
+      HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)a.nstrips * 64));
+      HIP_TRY(hipMemset(d_stamps, 0, (size_t)a.nstrips * 64));
+      a.stamps = d_stamps;
+    }
+    HIP_TRY(pw::launch_strip_fill(a, track, workers, lds_kb << 10, st));
+    if (d_stamps) {
+      std::vector<uint64_t> h((size_t)a.nstrips * 8);
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
+      (void)hipFree(d_stamps);
+      if (FILE* f = fopen(trace, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
+  }
   return 0;
 }
 
@@ -528,6 +632,10 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   static thread_local char name[96];
   int bk = 0, nw = 1; size_t most = 0;
   for (const auto& c : b->classes) if (c.order.size() > most) { most = c.order.size(); bk = c.bk; nw = c.nw; }
+  if (b->classes.empty() && b->tiled.empty() && !b->strips.empty()) {
+    snprintf(name, sizeof name, "k_fill_strip<%s> x row strips", b->endrule != pw::END_CORNER ? "true" : "false");
+    return name;
+  }
   if (b->classes.empty() && !b->tiled.empty()) { snprintf(name, sizeof name, "k_fill_tile<%s> x time blocks", b->use_f64 ? "double" : "int"); return name; }
   const char* t = b->use_f64 ? "double" : "int";
   if (nw > 1) { snprintf(name, sizeof name, "k_fill_mw<%s, %d, ...> x %d wavefronts", t, bk, nw); return name; }
@@ -581,8 +689,9 @@ int pw_batch_solve(pw_batch* b, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipSetDevice(b->device));
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_fill0, st));
-  const int rc = b->variant == pw::VAR_FAST16 ? launch_packed_fill(b, st)
-                 : b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
+  int rc = b->variant == pw::VAR_FAST16 ? launch_packed_fill(b, st)
+           : b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
+  if (rc == 0 && !b->strips.empty()) rc = launch_strip_fills(b, st);
   if (rc != 0) return rc;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_fill1, st)); b->fill_timed = true; }
   return 0;
@@ -595,6 +704,15 @@ static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
   p.transcripts = b->d_tx; p.npairs = b->n; p.gosign = b->gosign;
   p.banded = b->mode == pw::BANDED_MODE; p.ends = d_ends;
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_tr0, st));
+  for (int32_t k : b->strips) {        // strip-layout pairs: one wavefront each (before the fix-up pass below)
+    const pw::PairDesc& d = b->descs[k];
+    pw::StripTraceParams sp;
+    memset(&sp, 0, sizeof sp);
+    sp.masks = b->d_masks + d.mask_off; sp.result = b->d_results + k; sp.tx = b->d_tx + d.tx_off;
+    sp.ends = d_ends ? d_ends + 2 * k : nullptr;
+    sp.X = d.X; sp.Y = d.Y; sp.nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock; sp.tx_cap = d.tx_cap; sp.gosign = b->gosign;
+    HIP_TRY(pw::launch_strip_trace(sp, st));
+  }
   HIP_TRY(pw::launch_trace(p, st));
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_tr1, st)); b->trace_timed = true; }
   return 0;
@@ -645,6 +763,9 @@ int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap) 
 int pw_batch_results(pw_batch* b, pw_result* out) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->n) HIP_TRY(hipMemcpy(out, b->d_results, sizeof(pw_result) * (size_t)b->n, hipMemcpyDeviceToHost));
+  for (int32_t k : b->strips)
+    if ((out[k].status & PW_ST_BADPATH) && out[k].opt_i < 0)
+      return fail("the strip pipeline of a wide pair was abandoned (a wavefront waited too long for the strip above it)");
   return 0;
 }
 

@@ -63,6 +63,7 @@ typedef struct {
 #define PW_FLAG_PROFILE 8       /* bracket every fill launch with HIP events (pw_batch_fill_ms) */
 #define PW_FLAG_NO_PACKED16 16   /* never use the packed 16-bit steady-phase kernel (testing / A-B) */
 #define PW_FLAG_FORCE_TILED 32   /* run every pair through the time-blocked tiled kernel (testing) */
+#define PW_FLAG_FORCE_STRIP 64   /* run every pair that the strip pipeline supports through it (testing) */
 
 const char* pw_last_error(void);
 int pw_device_count(void);

@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ('pw_wave.h', 'pw_plan.h', 'pw_types.h')]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ('pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_types.h')]
     if force or not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         subprocess.check_call(['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-ffp-contract=off',
                                SRC, '-o', SO])
@@ -26,6 +26,7 @@ def lib():
         build()
         _lib = C.CDLL(SO)
         _lib.emu_solve.restype = C.c_int
+        _lib.emu_solve_strip.restype = C.c_int
     return _lib
 
 
@@ -88,4 +89,44 @@ def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., misma
         out['mutant_idx'] = info[7] + mrange[0]
     if want_table:
         out['hdump'] = hd
+    return out
+
+
+def solve_strip(origin, mutant, alntype=0, match=1., mismatch=0., go=0., ge=0., epoch=7, **_):
+    """Standard-mode problem through the strip pipeline (pw_strip.h): fill strip by strip, end-cell reduction, strip
+    walker, fix-up.  Same result dict as :func:`solve`."""
+    of = np.ascontiguousarray(np.asarray(origin, dtype=np.int32))
+    mf = np.ascontiguousarray(np.asarray(mutant, dtype=np.int32))
+    X, Y = len(of), len(mf)
+    if X == 0:
+        of = np.zeros(1, np.int32)
+    if Y == 0:
+        mf = np.zeros(1, np.int32)
+    info = (C.c_int * 10)()
+    score = C.c_double(0)
+    txcap = X + Y + 2
+    txbuf = C.create_string_buffer(txcap)
+    rc = lib().emu_solve_strip(alntype, of.ctypes.data_as(C.POINTER(C.c_int)), X, mf.ctypes.data_as(C.POINTER(C.c_int)), Y,
+                               C.c_double(match), C.c_double(mismatch), C.c_double(go), C.c_double(ge), C.c_uint(epoch),
+                               info, C.byref(score), txbuf, txcap)
+    if rc != 0:
+        raise ValueError('emu_solve_strip rc=%d' % rc)
+    out = dict(init_rc=info[0], opt=None, score=None, transcript=None, origin_idx=None,
+               mutant_idx=None, tb_null=None, would_panick=None)
+    if info[0] != 0:
+        return out
+    out['num_rows'] = info[3]
+    if info[4] < 0:
+        out['opt'] = (-1, -1)
+        return out
+    out['opt'] = (info[4], info[5])
+    out['score'] = score.value
+    st = info[9]
+    out['would_panick'] = bool(st & 4)
+    out['tb_null'] = bool(st & 2) and not (st & 4)
+    out['badpath'] = bool(st & 8)
+    if not (st & 4) and not (st & 2):
+        out['transcript'] = txbuf.value.decode('ascii')
+        out['origin_idx'] = info[6]
+        out['mutant_idx'] = info[7]
     return out

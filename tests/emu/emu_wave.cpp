@@ -16,6 +16,7 @@
 
 #define PW_FN inline
 #include "../../biseqt_amd/csrc/pw_wave.h"
+#include "../../biseqt_amd/csrc/pw_strip.h"
 #include "../../biseqt_amd/csrc/pw_plan.h"
 
 namespace {
@@ -85,6 +86,39 @@ struct EmuP {
   static bool central() { return true; }
   static constexpr bool kVirtualLanes = false;
   static constexpr bool kBatchedShifts = false;
+};
+
+// the strip pipeline (pw_strip.h): same lanes; the FIFO between strips is plain memory (strips run one after another)
+struct EmuPS : EmuP {
+  static bool all(bool p) {
+    int v = p ? 1 : 0;
+    for (int off = 32; off >= 1; off >>= 1) v &= shfl_xor(v, off);
+    return v != 0;
+  }
+  static uint32_t readlane(uint32_t v, int i) { Emu* e = Emu::self; return (uint32_t)e->exchange((int)v, i, 0); }
+  static uint64_t fifo_load(const uint64_t* p) { return *p; }
+  static uint64_t fifo_poll(const uint64_t* p) { return *p; }
+  static uint64_t fifo_load_local(const uint64_t* p) { return *p; }
+  static uint32_t flag_poll(const uint32_t* p) { return *p; }
+  static void fifo_store(uint64_t* p, uint64_t v) { *p = v; }
+  static void fifo_store_local(uint64_t* p, uint64_t v) { *p = v; }
+  static void sleep() {}
+  static uint64_t ballot(bool p) {
+    Emu* e = Emu::self;
+    const int l = e->cur;
+    const unsigned ph = e->phase[l]++ & 1u;
+    e->xch[ph][l] = p ? 1 : 0;
+    e->barrier();
+    e->cur = l;
+    uint64_t m = 0;
+    for (int j = 0; j < Emu::N; j++) if (e->xch[ph][j]) m |= (uint64_t)1 << j;
+    return m;
+  }
+  static void wave_sync() { Emu* e = Emu::self; (void)e->exchange(0, e->cur, 0); }
+  static uint64_t clock() { return 0; }
+  static int32_t in_vgpr(int32_t v) { return v; }
+  static uint32_t flag_load(const uint32_t* p) { return *p; }
+  static void flag_set(uint32_t* p) { *p = 1u; }
 };
 
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
@@ -222,6 +256,69 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
 }
 
 }  // namespace
+
+// Standard-mode problem through the strip pipeline: strips in index order, end-cell reduction, strip walker, fix-up.
+extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mutant, int Y, double match, double mismatch,
+                               double go, double ge, unsigned epoch, int* info, double* score, char* txbuf, int txcap) {
+  pw::Plan pl = pw::plan_problem(pw::STD_MODE, type, X, Y, 0, 0);
+  info[0] = pl.rc; info[1] = pl.dmin; info[2] = pl.dmax; info[3] = pl.num_rows;
+  info[4] = -1; info[5] = -1; info[6] = 0; info[7] = 0; info[8] = 0; info[9] = 0;
+  if (pl.rc != 0) return 0;
+  const int opad = ((X > 0 ? X : 1) + 31) / 16 * 16;
+  const int mpad = ((Y > 0 ? Y : 1) + 31) / 16 * 16;
+  std::vector<uint8_t> arena(opad + mpad, 0);
+  for (int i = 0; i < X; i++) arena[i] = (uint8_t)origin[i];
+  for (int i = 0; i < Y; i++) arena[opad + i] = (uint8_t)mutant[i];
+  pw::StripParams a;
+  memset(&a, 0, sizeof a);
+  a.arena = arena.data(); a.o_off = 0; a.m_off = opad;
+  a.X = X; a.Y = Y;
+  a.nstrips = (X + 1 + 63) / 64;
+  a.nkq = (Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
+  a.fifo_pitch = (Y + 1 + 63) / 64 * 64;
+  std::vector<uint64_t> fifo((size_t)a.nstrips * a.fifo_pitch, 0x00000000deadbeefull);   // stale granules of "earlier solves"
+  for (size_t i = 0; i < fifo.size(); i += 3) fifo[i] = ((uint64_t)(epoch - 1) << 32) | 12345u;
+  std::vector<uint32_t> masks((size_t)a.nstrips * a.nkq * 64 * 4, 0xdeadbeefu);
+  std::vector<pw::StripBest> sbest(a.nstrips);
+  uint32_t ctl[16] = {0};
+  pw::Result res;
+  memset(&res, 0, sizeof res);
+  a.fifo = fifo.data(); a.masks = masks.data(); a.sbest = sbest.data(); a.ctl = ctl; a.result = &res;
+  a.epoch = epoch; a.brule = pl.brule; a.endrule = pl.endrule;
+  a.match = (int32_t)match; a.mismatch = (int32_t)mismatch; a.go = (int32_t)go; a.ge = (int32_t)ge;
+  a.spin_limit = 4;
+  const bool track = pl.endrule != pw::END_CORNER;
+  for (int w = 0; w < a.nstrips; w++) {
+    Emu emu;
+    bool ok = true;
+    if (track) emu.run([&]() { pw::StripFill<EmuPS, true> f(a); if (!f.run(w, (w & 1) == 0, (w & 1) != 0)) ok = false; });
+    else emu.run([&]() { pw::StripFill<EmuPS, false> f(a); if (!f.run(w, (w & 1) == 0, (w & 1) != 0)) ok = false; });
+    if (!ok) return -7;
+  }
+  { Emu emu; emu.run([&]() { pw::strip_reduce<EmuPS>(a); }); }
+  std::vector<uint8_t> tx((size_t)(X + Y + 1) + 1, 0);
+  pw::StripTraceParams tp;
+  memset(&tp, 0, sizeof tp);
+  tp.masks = masks.data(); tp.result = &res; tp.tx = tx.data(); tp.ends = nullptr;
+  tp.X = X; tp.Y = Y; tp.nkq = a.nkq; tp.tx_cap = X + Y + 1; tp.gosign = go < 0 ? -1 : (go > 0 ? 1 : 0);
+  std::vector<uint32_t> win(pw::kWalkWinWords, 0);
+  { Emu emu; emu.run([&]() { pw::strip_walk<EmuPS>(tp, win.data()); }); }
+  pw::PairDesc pd;
+  memset(&pd, 0, sizeof pd);
+  pd.o_off = 0; pd.m_off = opad; pd.X = X; pd.Y = Y; pd.tx_off = 0; pd.tx_cap = X + Y + 1; pd.solvable = 1;
+  pw::TraceParams fp;
+  memset(&fp, 0, sizeof fp);
+  fp.pairs = &pd; fp.arena = arena.data(); fp.results = &res; fp.transcripts = tx.data(); fp.npairs = 1;
+  pw::trace_fixup_serial(fp, 0);
+  info[4] = res.opt_i; info[5] = res.opt_j; info[6] = res.origin_idx; info[7] = res.mutant_idx;
+  info[8] = res.tx_len; info[9] = res.status;
+  *score = res.score;
+  if (res.tx_len > 0 && res.tx_len < txcap) {
+    memcpy(txbuf, tx.data() + pd.tx_cap - res.tx_len, (size_t)res.tx_len);
+    txbuf[res.tx_len] = 0;
+  } else if (txcap > 0) txbuf[0] = 0;
+  return 0;
+}
 
 extern "C" int emu_solve(int mode, int type, const int* origin, int X, const int* mutant, int Y, int L,
                          const double* subst, double go, double ge, int dmin, int dmax, int use_double,

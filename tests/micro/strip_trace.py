@@ -1,0 +1,40 @@
+"""Per-strip timeline of the strip pipeline (PWLIB_STRIP_TRACE): where a hop's time goes.
+
+    python tests/micro/strip_trace.py X Y
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, 'gpurun_out', 'strip_trace.bin')
+os.environ['PWLIB_STRIP_TRACE'] = out
+from biseqt_amd import synth, _pwlib as W          # noqa: E402
+from biseqt_amd.batch import BatchAligner          # noqa: E402
+
+X, Y = int(sys.argv[1]), int(sys.argv[2])
+rng = synth.rng_for(33)
+o = synth.rand_seqs(rng, 1, X)[0]
+m = synth.rand_seqs(rng, 1, Y)[0]
+with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2,
+                  flags=W.PW_FLAG_PROFILE | W.PW_FLAG_FORCE_STRIP) as b:
+    b.solve(); b.sync()
+    b.solve(); b.sync()
+    print('fill %.3f ms' % b.fill_ms())
+t = np.fromfile(out, dtype=np.uint64).reshape(-1, 8)
+t0 = t[:, 0].min()
+us = (t[:, :6].astype(np.int64) - int(t0)) / 100.0
+xcc = (t[:, 7] & 0xff).astype(int)
+names = ['dequeue', 'setup', 'granules seen', 'step 64', 'step 96', 'end']
+print('strips %d; columns: %s (us since the first dequeue)' % (len(t), ', '.join(names)))
+for w in list(range(0, min(len(t), 12))) + list(range(124, min(len(t), 134))) + list(range(len(t) - 3, len(t))):
+    if 0 <= w < len(t):
+        print('strip %5d xcc %d  ' % (w, xcc[w]) + '  '.join('%9.2f' % v for v in us[w]))
+d = np.diff(us[:, 2])
+print('hop (granules seen, w -> w+1): median %.2f us, mean %.2f, p90 %.2f; same-XCD hops %.2f, cross-XCD %.2f'
+      % (np.median(d), d.mean(), np.percentile(d, 90), np.median(d[xcc[1:] == xcc[:-1]]) if (xcc[1:] == xcc[:-1]).any() else -1,
+         np.median(d[xcc[1:] != xcc[:-1]]) if (xcc[1:] != xcc[:-1]).any() else -1))
+print('granules seen -> step 64: median %.2f us; step 64 -> 96: %.2f us; strip total: %.2f us'
+      % (np.median(us[:, 3] - us[:, 2]), np.median(us[:, 4] - us[:, 3]), np.median(us[:, 5] - us[:, 2])))

@@ -524,24 +524,44 @@ def test_tiled_kernel_forced(oracle):
                     assert txs[1] == r2['transcript'], kw
 
 
-def test_tiled_kernel_natural_vs_oracle(oracle):
-    """A table wider than one workgroup holds (9000 x ~9000 standard mode, 18 000 diagonals) goes to the tiled kernel
-    by itself; the oracle still fits (8e7 cells): score, end cell, start and transcript must be identical."""
-    from biseqt_amd import synth
+def test_wide_table_kernels_natural_vs_oracle(oracle):
+    """A table wider than one workgroup holds (9000 x ~9000 standard mode, 18 000 diagonals) goes by itself to the
+    strip pipeline (K2c: integer scores, simple scoring) or to the tiled kernel (K2b: f64 here); the oracle still
+    fits (8e7 cells): score, end cell, start and transcript must be identical.  The wide pair shares its batch with
+    small pairs that take the ordinary one-wavefront kernel."""
+    from biseqt_amd import synth, _pwlib as W
     from biseqt_amd.batch import BatchAligner
     rng = synth.rng_for(31)
     o = synth.rand_seqs(rng, 1, 9000)[0]
     m = synth.mutate(rng, o, 0.07, 0.015, 0.5)
-    for alntype in (1, 4):              # LOCAL, OVERLAP
-        with BatchAligner([(o, m)], alnmode=0, alntype=alntype, alphabet_len=4, match_score=1, mismatch_score=-3,
-                          go_score=-5, ge_score=-2) as b:
-            assert 'tile' in b.kernel_name
+    small = [(o[:300], m[:310]), (m[:90], o[:70])]
+    for alntype, flags, kernel in ((1, 0, 'strip'), (4, 0, 'strip'), (0, 0, 'strip'), (1, W.PW_FLAG_FORCE_F64, 'tile')):
+        with BatchAligner([small[0], (o, m), small[1]], alnmode=0, alntype=alntype, alphabet_len=4, match_score=1,
+                          mismatch_score=-3, go_score=-5, ge_score=-2, flags=flags) as b:
             res = b.run()
-            tx = b.transcripts(res)[0]
-        r = oracle.solve(o, m, L=4, mode=0, alntype=alntype, match=1, mismatch=-3, go=-5, ge=-2)
-        assert (res['opt_i'][0], res['opt_j'][0]) == r['opt']
-        assert res['score'][0] == r['score'] and tx == r['transcript']
-        assert (res['origin_idx'][0], res['mutant_idx'][0]) == (r['origin_idx'], r['mutant_idx'])
+            txs = b.transcripts(res)
+        with BatchAligner([(o, m)], alnmode=0, alntype=alntype, alphabet_len=4, match_score=1,
+                          mismatch_score=-3, go_score=-5, ge_score=-2, flags=flags) as b:
+            assert kernel in b.kernel_name, b.kernel_name
+        for k, (oo, mm) in enumerate([small[0], (o, m), small[1]]):
+            r = oracle.solve(oo, mm, L=4, mode=0, alntype=alntype, match=1, mismatch=-3, go=-5, ge=-2)
+            assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'], (alntype, k)
+            if r['opt'][0] != -1:
+                assert res['score'][k] == r['score'] and txs[k] == r['transcript'], (alntype, k)
+                assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx'])
+
+
+def test_strip_pipeline_forced_on_small_tables(oracle):
+    """The strip pipeline (K2c, pw_strip.h) forced on standard-mode tables the oracle can check: all seven alignment
+    types, seven score sets (linear and affine gaps, mismatch above match), 1 - 3 pairs per batch running one after
+    another, every batch solved twice (FIFO granules of the first solve must never pass for fresh ones), tables from
+    empty to 40 strips."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('strip_check', os.path.join(os.path.dirname(__file__), 'micro', 'strip_check.py'))
+    sc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sc)
+    assert sc.run(cases=120, seed=20261004, maxlen=900) == 0
+    assert sc.run(cases=20, seed=20261005, maxlen=2600) == 0
 
 
 def test_config3_full_size_properties():
@@ -557,13 +577,21 @@ def test_config3_full_size_properties():
     m = synth.mutate(rng, o, 0.07, 0.015, 0.5)
     with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1, mismatch_score=-3,
                       go_score=-5, ge_score=-2) as b:
-        assert 'tile' in b.kernel_name and b.cells == (len(o) + 1) * (len(m) + 1)
+        assert 'strip' in b.kernel_name and b.cells == (len(o) + 1) * (len(m) + 1)
         res = b.run()
         tx = b.transcripts(res)[0]
     s, i, j = _rescore(o, m, tx, int(res['origin_idx'][0]), int(res['mutant_idx'][0]), 1, -3, -5, -2)
     assert s == res['score'][0] and s > 30000
     assert (i, j) == (int(res['opt_i'][0]), int(res['opt_j'][0]))
     assert tx[0] in 'MS' and tx[-1] in 'MS'                  # a local alignment never starts or ends with a gap
+    # two independent kernels, one answer: the time-blocked tiled kernel (diagonal lanes, ghost zones) at full size
+    from biseqt_amd import _pwlib as W
+    with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1, mismatch_score=-3,
+                      go_score=-5, ge_score=-2, flags=W.PW_FLAG_FORCE_TILED) as b:
+        assert 'tile' in b.kernel_name
+        res2 = b.run()
+        tx2 = b.transcripts(res2)[0]
+    assert (res2 == res).all() and tx2 == tx
 
 
 def test_band_edge_never_leaks_long_pairs(oracle):
