@@ -182,3 +182,35 @@ def test_emu_packed16_overlap_last_cell_on_a_block_boundary(oracle):
         a = oracle.solve(o, m, **kw)
         b = emu.solve(o, m, bk=4, packed16=2, **kw)
         assert a['opt'] == b['opt'] and a['score'] == b['score'] and a['transcript'] == b['transcript'], hi
+
+
+def test_emu_strip_pipeline(oracle):
+    """The strip pipeline's lane program (pw_strip.h: row strips, FIFO hand-off, end-cell reduction, ballot-driven walker)
+    on the CPU emulator against the oracle: all seven standard-mode types, linear / affine gaps, tables from empty to a
+    dozen strips (so that start, steady and general blocks, stale FIFO granules and both store flavours all occur)."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(2026)
+    scores = [(1, -3, -5, -2), (1, 0, 0, 0), (2, -1, 0, -1), (5, -4, -10, -1), (1, -1, -1, -1), (1, -3, 0, -2), (1, 6, -5, -2)]
+    n = 0
+    for trial in range(84):
+        big = trial % 6 == 0
+        X = int(rng.integers(200, 800)) if big else (int(rng.integers(0, 200)) if trial % 5 else int(rng.integers(0, 6)))
+        o = rng.integers(0, 4, X).astype(np.uint8)
+        kind = trial % 4
+        if kind == 0:
+            m = synth.mutate(rng, o, 0.1, 0.05, 0.3) if X else rng.integers(0, 4, int(rng.integers(0, 9))).astype(np.uint8)
+        elif kind == 1:
+            k = int(rng.integers(0, X + 1))
+            m = np.concatenate([o[k:], rng.integers(0, 4, int(rng.integers(0, 90))).astype(np.uint8)])
+        elif kind == 2:
+            m = rng.integers(0, 4, int(rng.integers(0, 300))).astype(np.uint8)
+        else:
+            m = o.copy()
+        sc = scores[trial % len(scores)]
+        kw = dict(L=4, mode=0, alntype=trial % 7, match=float(sc[0]), mismatch=float(sc[1]), go=float(sc[2]), ge=float(sc[3]))
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve_strip(o, m, epoch=3 + trial, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
+        n += 1
+    assert n == 84
