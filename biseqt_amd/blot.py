@@ -329,17 +329,44 @@ class _RefMixin(object):
         self._base.__init__(self, self.S, seq, g_max=g_max, sensitivity=sensitivity, **kw)
         self._perm = None
 
+    def _points(self):
+        """The (d, a) points the class works on, in the order the device lists them: the table rows, or -- when the
+        query IS the reference (``blot.py:612``: trivial seeds skipped, every other pair met from both sides) -- each
+        non-trivial row followed by its mirror image."""
+        rows = self.rows().astype(np.int64)
+        if not self.self_comp:
+            return rows
+        nt = rows[rows[:, 0] != 0]
+        pts = np.empty((2 * len(nt), 2), np.int64)
+        pts[0::2] = nt
+        pts[1::2] = nt * np.array([-1, 1])
+        return pts
+
     def _presentation(self):
         if self._perm is None:
-            rows = self.rows().astype(np.int64)
-            i, j = (rows[:, 1] + rows[:, 0]) // 2, (rows[:, 1] - rows[:, 0]) // 2
+            pts = self._points()
+            i, j = (pts[:, 1] + pts[:, 0]) // 2, (pts[:, 1] - pts[:, 0]) // 2
             self._perm = np.lexsort((i, j))
         return self._perm
 
     def seeds(self, exclude_trivial=True):
         assert self.T is not None
-        rows = self.rows().astype(np.int64)[self._presentation()]
-        return list(zip(((rows[:, 1] + rows[:, 0]) // 2).tolist(), ((rows[:, 1] - rows[:, 0]) // 2).tolist()))
+        pts = self._points()[self._presentation()]
+        return list(zip(((pts[:, 1] + pts[:, 0]) // 2).tolist(), ((pts[:, 1] - pts[:, 0]) // 2).tolist()))
+
+    def seed_count(self, d_band=None, a_band=None):
+        """The in-memory classes count their own seed list (``blot.py:622-637, 683-698``), not table rows: for a self
+        comparison that is every non-trivial row and its mirror image."""
+        if not self.self_comp:
+            return self._base.seed_count(self, d_band=d_band, a_band=a_band)
+
+        def nontrivial(db):
+            c = self._idx.count(db, a_band)
+            if db is None or db[0] <= 0 <= db[1]:
+                c -= self._idx.count((0, 0), a_band)
+            return c
+        mirror = None if d_band is None else (-d_band[1], -d_band[0])
+        return nontrivial(d_band) + nontrivial(mirror)
 
 
 class WordBlotLocalRef(_RefMixin, WordBlot):

@@ -82,7 +82,15 @@ PW_FN uint64_t strip_mask_index(int nkq, int w, int q, int lane) {      // in dw
 template <class P, bool TRACK>
 struct StripFill {
   static constexpr int32_t NEG = -(1 << 28);       // "no such predecessor" (pw_wave.h, ScoreTraits<int32_t>)
-  static constexpr int SUB = 8;                    // FIFO granules per hand-off (one store / one load of 8 lanes)
+#ifndef PW_STRIP_ROLL_START
+#define PW_STRIP_ROLL_START 1     /* steps 0 .. 63 as a rolled loop: same speed as unrolled (measured), a third of the code */
+#endif
+#ifndef PW_STRIP_SUB
+#define PW_STRIP_SUB 16    /* measured: 16 -> 33.9 ms, 8 -> 35.8 ms on config 3 (one wait for memory per hand-off) */
+#endif
+  static constexpr int SUB = PW_STRIP_SUB;         // FIFO granules per hand-off (one store / one load of SUB lanes)
+  static constexpr int NSB = kStripBlock / SUB;    // hand-offs per block
+  static_assert(SUB == 8 || SUB == 16, "hand-off size");
   const StripParams& a;
   int lane, w, x;
   // per lane: the cell computed last (H, what it offers downwards / rightwards), the diagonal predecessor of the
@@ -172,11 +180,11 @@ struct StripFill {
     gP = P::shl1(gP, Hn + Hn + (bD ? 1 : 0));
   }
 
-  // After the 8 steps k0 .. k0 + 7: lane 56 + j holds lane 63's cell of step k0 + j, column y = k0 + j - 63.
+  // After the SUB steps k0 .. k0 + SUB - 1: lane 64 - SUB + j holds lane 63's cell of step k0 + j, column y = k0 + j - 63.
   PW_FN void flush_out(int k0) {
     if (fout == nullptr) return;
-    const int y = k0 + (lane - 56) - 63;
-    if (lane >= 56 && y >= 0 && y <= a.Y) {
+    const int y = k0 + (lane - (64 - SUB)) - 63;
+    if (lane >= 64 - SUB && y >= 0 && y <= a.Y) {
       const uint64_t g = ((uint64_t)a.epoch << 32) | (uint64_t)(uint32_t)gP;
       if (cross_out) P::fifo_store(fout + y, g);
       else P::fifo_store_local(fout + y, g);
@@ -220,8 +228,8 @@ struct StripFill {
   // (loaded 16 steps ago; the load for 16 steps further on is issued right away), then the steps, then what lane 63
   // produced goes out.
   template <int MODE, int J>
-  PW_FN bool sub_block(int q, uint32_t& m) {
-    const int S = 4 * q + J;
+  PW_FN bool sub_block(int q, uint32_t (&mw)[4]) {
+    const int S = NSB * q + J;
     const int k0 = kStripBlock * q + SUB * J;
     if (fin != nullptr) {
       if (J & 1) { if (!merge_sub(tE, S + 1, SUB)) return false; tE = load_sub(S + 3, SUB); }
@@ -231,13 +239,17 @@ struct StripFill {
     // vmcnt(0) wherever a load result is used while a store is in flight (loads and stores share the counter), so the
     // only memory operations in flight at that wait should be ones issued 8 steps earlier
     flush_out(k0 - SUB);
-    m = 0;
-    if (MODE == 2) {
-#pragma unroll 1
-      for (int s = 0; s < SUB; s++) step<2>(k0 + s, m);
-    } else {
 #pragma unroll
-      for (int s = 0; s < SUB; s++) step<MODE>(k0 + s, m);
+    for (int h = 0; h < SUB / 8; h++) {                  // one mask dword per 8 steps
+      uint32_t m = 0;
+      if (MODE == 2 || (MODE == 1 && PW_STRIP_ROLL_START)) {
+#pragma unroll 1
+        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m);
+      }
+      mw[J * (SUB / 8) + h] = m;
     }
     return true;
   }
@@ -246,10 +258,12 @@ struct StripFill {
     cM = nM;
     nM = load_letters(q + 1);
     uint32_t mw[4];
-    if (!sub_block<MODE, 0>(q, mw[0])) return false;
-    if (!sub_block<MODE, 1>(q, mw[1])) return false;
-    if (!sub_block<MODE, 2>(q, mw[2])) return false;
-    if (!sub_block<MODE, 3>(q, mw[3])) return false;
+    if (!sub_block<MODE, 0>(q, mw)) return false;
+    if (!sub_block<MODE, 1>(q, mw)) return false;
+    if (NSB == 4) {
+      if (!sub_block<MODE, 2>(q, mw)) return false;
+      if (!sub_block<MODE, 3>(q, mw)) return false;
+    }
     U4 v; v.x = mw[0]; v.y = mw[1]; v.z = mw[2]; v.w = mw[3];
     *(U4*)(a.masks + strip_mask_index(a.nkq, w, q, lane)) = v;
     return true;

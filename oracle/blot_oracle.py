@@ -111,6 +111,23 @@ def _seed_list(S, T, wordlen, alphabet_len, mask, order):
     return SO.seeds(rows, self_comp, exclude_trivial=True)
 
 
+def _seed_count(S, T, wordlen, alphabet_len, mask, order, d_band=None, a_band=None):
+    """`seed_count` as the class at hand counts: the SQL classes count rows of the seeds table (seeds.py:199-231), the
+    in-memory *Ref classes iterate their own `seeds()` list, trivial seeds excluded (blot.py:622-637, 683-698)."""
+    if order != 'mutant':
+        rows, _ = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
+        return SO.seed_count(rows, d_band=d_band, a_band=a_band)
+    cnt = 0
+    for i, j in _seed_list(S, T, wordlen, alphabet_len, mask, order):
+        d, a = SO.to_diagonal_coordinates(i, j)
+        if d_band and not d_band[0] <= d <= d_band[1]:
+            continue
+        if a_band and not a_band[0] <= a <= a_band[1]:
+            continue
+        cnt += 1
+    return cnt
+
+
 def score_seeds(S, T, wordlen, alphabet_len, g_max, sensitivity, mask=(), order='table'):
     ij = _seed_list(S, T, wordlen, alphabet_len, mask, order)
     all_seeds = [SO.to_diagonal_coordinates(i, j) for i, j in ij]
@@ -147,8 +164,7 @@ def highest_scoring_overlap_band(S, T, wordlen, alphabet_len, g_max, sensitivity
     res = {'d_band': d_band, 'p': p_hat, 'len': overlap_len}
     area = 2 * rad * overlap_len
     mu_H1, sd_H1 = H1_moments(alphabet_len, wordlen, area, overlap_len, p_hat)
-    rows, _ = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
-    num_seeds = SO.seed_count(rows, d_band=d_band)
+    num_seeds = _seed_count(S, T, wordlen, alphabet_len, mask, order, d_band=d_band)
     res['score'] = (num_seeds - mu_H1) / sd_H1
     return res
 
@@ -210,7 +226,6 @@ def similar_segments(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, p_m
                      order='table'):
     """blot.py:410-490, the depth-first growth included (the order of `ps_in_seg`, and with it the last bits of the
     averaged p, follows the KD-tree's neighbour order)."""
-    rows, _ = SO.seed_rows(S, T, wordlen, alphabet_len, mask)
     d_radius = int(np.ceil(band_radius(K_min, g_max, sensitivity)))
     a_radius = K_min
     scored = score_seeds_local(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, mask, order)
@@ -247,7 +262,7 @@ def similar_segments(S, T, wordlen, alphabet_len, g_max, sensitivity, K_min, p_m
         a_min = max(a_min, 0); a_max = min(a_max, lenS + lenT)
         seg = (d_min, d_max), (a_min, a_max)
         p_hat = sum(ps) / len(ps)
-        n = SO.seed_count(rows, d_band=seg[0], a_band=seg[1])
+        n = _seed_count(S, T, wordlen, alphabet_len, mask, order, d_band=seg[0], a_band=seg[1])
         K_hat, area_hat = segment_dims(seg[0], seg[1])
         out.append({'segment': seg, 'p': p_hat,
                     'scores': score_num_seeds(n, area_hat, K_hat, p_hat, alphabet_len, wordlen)})

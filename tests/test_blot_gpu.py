@@ -1,6 +1,8 @@
 """GPU band selection (biseqt_amd.blot.WordBlotOverlap over include/pw_seeds.h) against the oracle, which runs the
 reference's own neighbour search (scipy cKDTree) on the CPU; and the reference's overlap-detection test
 (tests/test_blot.py:160-197) end to end: seeds -> band -> banded overlap alignment on the GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -206,3 +208,63 @@ def test_self_similarity_vs_oracle():
                 assert abs(g['p'] - e['p']) <= 1e-12 * max(abs(e['p']), 1e-300)
                 assert np.allclose(g['scores'], e['scores'], rtol=1e-9, atol=0)
         wb.close()
+
+
+def _fx(h):
+    return float.fromhex(h)
+
+
+def test_ref_classes_equal_the_reference_fixtures():
+    """WordBlotOverlapRef / WordBlotLocalRef of the product against results of the REFERENCE's own classes
+    (tests/golden/blot_classes.json, generated by make_blot_golden.py from /root/reference/biseqt/blot.py): every seed's
+    r / L / p and neighbour set, the best overlap band with its z-score, the local segments in order with their averaged
+    p (1e-12: the reference's float sum follows its KD-tree's neighbour order) and z-scores (1e-9, where the reference's
+    python-2 integer division cannot have differed)."""
+    import json
+    from biseqt_amd.blot import WordBlotLocalRef, WordBlotOverlapRef
+    from biseqt_amd.sequence import Alphabet
+    A = Alphabet('ACGT')
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'blot_classes.json')) as f:
+        R = json.load(f)['records']
+    for k, r in enumerate(R['overlap']):
+        S, T = [int(c) for c in r['S']], [int(c) for c in r['T']]
+        if S == T:
+            continue           # documented divergence: the overlap classes refuse to compare a sequence with itself
+        ovl = WordBlotOverlapRef(_mk(A, np.array(S)), wordlen=r['wordlen'], alphabet=A, g_max=_fx(r['g_max']),
+                                 sensitivity=_fx(r['sensitivity']))
+        Tq = _mk(A, np.array(T))
+        got = ovl.score_seeds_(Tq)
+        assert len(got) == len(r['score_seeds']), k
+        for a, b in zip(got, r['score_seeds']):
+            assert [a['seed'][0], a['seed'][1]] == b['seed'] and float(a['r']).hex() == b['r'], k
+            assert a['L'] == b['L'] and float(a['p']).hex() == b['p'], k
+        best = ovl.highest_scoring_overlap_band(Tq)
+        if r['best'] is None:
+            assert best is None
+        else:
+            assert [float(best['d_band'][0]).hex(), float(best['d_band'][1]).hex()] == r['best']['d_band'], k
+            assert float(best['p']).hex() == r['best']['p'] and best['len'] == r['best']['len'], k
+            assert float(best['score']).hex() == r['best']['score'], k
+        ovl.close()
+    nseg = 0
+    for k, r in enumerate(R['local']):
+        S, T = [int(c) for c in r['S']], [int(c) for c in r['T']]
+        loc = WordBlotLocalRef(_mk(A, np.array(S)), wordlen=r['wordlen'], alphabet=A, g_max=_fx(r['g_max']),
+                               sensitivity=_fx(r['sensitivity']))
+        Tq = _mk(A, np.array(T))
+        got = loc.score_seeds_(Tq, r['K_min'])
+        assert len(got) == len(r['score_seeds']), k
+        for a, b in zip(got, r['score_seeds']):
+            assert [a['seed'][0], a['seed'][1]] == b['seed'], k
+            assert sorted(int(v) for v in a['neighs']) == b['neighs'] and float(a['p']).hex() == b['p'], k
+        segs = list(loc.similar_segments(Tq, r['K_min'], _fx(r['p_min']), at_least_one=r['at_least_one']))
+        assert len(segs) == len(r['segments']), k
+        for a, b in zip(segs, r['segments']):
+            assert [list(a['segment'][0]), list(a['segment'][1])] == b['segment'], k
+            assert abs(a['p'] - _fx(b['p'])) <= 1e-12 * abs(_fx(b['p'])), k
+            if b['scores_py2_safe']:
+                for u, v in zip(a['scores'], b['scores']):
+                    assert abs(u - _fx(v)) <= 1e-9 * max(1.0, abs(_fx(v))), k
+            nseg += 1
+        loc.close()
+    assert nseg >= 6
