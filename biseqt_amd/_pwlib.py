@@ -145,6 +145,43 @@ def check_layout():
 _lib = None
 
 
+def _bind_hip_runtime():
+    """One HIP runtime per process.  ``pwlib.so`` needs ``libamdhip64.so.7``; a PyTorch wheel bundles its own copy of
+    that library (same SONAME) and two HIP / HSA runtimes in one process cannot both find the GPU.  If ``pwlib.so`` is
+    loaded first it would pull in the system runtime and a later ``import torch`` would bring the second one, so when a
+    torch installation with a bundled runtime exists and none is mapped yet, that copy is loaded first (RTLD_GLOBAL):
+    ``pwlib.so`` then binds to it by SONAME, and torch, imported later or never, finds its own library already there.
+    ``PWLIB_HIP_RUNTIME=system`` keeps the system runtime, ``PWLIB_HIP_RUNTIME=/path/libamdhip64.so`` picks one."""
+    import sys
+    choice = os.environ.get('PWLIB_HIP_RUNTIME', '')
+    if choice == 'system':
+        return None
+    try:
+        with open('/proc/self/maps') as f:
+            if 'libamdhip64' in f.read():
+                return None                      # a runtime is mapped already (torch imported first): bind to it
+    except OSError:
+        pass
+    path = choice
+    if not path:
+        if 'torch' in sys.modules:
+            return None
+        try:
+            import importlib.util
+            spec = importlib.util.find_spec('torch')             # locates the package without importing it
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return None
+        path = os.path.join(os.path.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if not os.path.exists(path):
+        return None
+    try:
+        return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def load():
     """dlopen pwlib.so and declare its prototypes.  Raises if the library has not been built."""
     global _lib
@@ -153,6 +190,7 @@ def load():
     if not os.path.exists(PWLIB_SO):
         raise ImportError('%s is missing: build it with `python -m biseqt_amd.csrc.build` '
                           '(hipcc, gfx950); there is no CPU fallback' % PWLIB_SO)
+    _bind_hip_runtime()
     lib = C.CDLL(PWLIB_SO)
     P = C.POINTER
     lib.dptable_init.argtypes = [P(dptable)]

@@ -27,6 +27,21 @@ static inline int plan_len(int X, int Y, int d) {       // cells on diagonal d (
   return 1 + (d > 0 ? 0 : d) + (X - d > Y ? Y : X - d);
 }
 
+// sum over d = dmin .. dmax of plan_len(X, Y, d) in closed form (dmin <= dmax, -Y <= dmin, dmax <= X): three
+// arithmetic series -- the number of diagonals, min(d, 0) over the negative ones, min(X - d, Y) split at d = X - Y.
+static inline int64_t plan_series(int64_t a, int64_t b) { return a > b ? 0 : (a + b) * (b - a + 1) / 2; }   // a + ... + b
+static inline int64_t plan_band_cells(int X, int Y, int dmin, int dmax) {
+  const int64_t n = (int64_t)dmax - dmin + 1;
+  int64_t cells = n;
+  cells += plan_series(dmin, dmax < -1 ? dmax : -1);                      // min(d, 0)
+  const int64_t k = (int64_t)X - Y;                                       // X - d > Y  <=>  d < k
+  const int64_t lo_end = dmax < k - 1 ? dmax : k - 1;                     // d in [dmin, lo_end]: min = Y
+  if (lo_end >= dmin) cells += (lo_end - dmin + 1) * (int64_t)Y;
+  const int64_t hi_beg = dmin > k ? dmin : k;                             // d in [hi_beg, dmax]: min = X - d
+  if (hi_beg <= dmax) cells += (dmax - hi_beg + 1) * (int64_t)X - plan_series(hi_beg, dmax);
+  return cells;
+}
+
 // Begin rule (_alnchoice_B, _pw_internals.c:161-209) and end rule (:303-414) of an alignment type.
 static inline void plan_rules(int mode, int type, int* brule, int* endrule) {
   if (mode == STD_MODE) {
@@ -61,8 +76,7 @@ static inline Plan plan_problem(int mode, int type, int X, int Y, int dmin_in, i
     p.num_rows = 1 + dmax - dmin;
     if (p.num_rows < 0) { p.rc = -1; return p; }       // :46-49
     if (p.num_rows == 0) { p.ndiag = 0; return p; }    // an empty table: the reference goes on with zero rows
-    // closed form of sum_d (1 + min(d,0) + min(X-d, Y)); a loop is fine (num_rows <= X+Y+1)
-    for (int d = dmin; d <= dmax; d++) p.cells += plan_len(X, Y, d);
+    p.cells = plan_band_cells(X, Y, dmin, dmax);
   }
   p.ndiag = 1 + p.dmax - p.dmin;
   // first / last anti-diagonal that holds an in-band cell

@@ -793,3 +793,38 @@ def test_buffer_pool_reuse_and_trim():
     assert marks[1] - base > 50                           # ... because the buffers are parked in the pool
     lib.pw_pool_trim()
     assert used() - base < 32
+
+
+def test_library_loaded_before_torch_still_sees_the_device():
+    """One HIP runtime per process whatever the import order: a fresh interpreter loads pwlib.so FIRST, solves a batch,
+    then imports torch, which must find the same device, and the library must keep working afterwards."""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from biseqt_amd import _pwlib as W
+from biseqt_amd.batch import BatchAligner
+lib = W.load()
+assert 'torch' not in sys.modules
+assert lib.pw_device_count() >= 1
+pairs = [(np.array([0, 1, 2, 3, 0, 1], np.uint8), np.array([0, 1, 3, 3, 0, 1], np.uint8))] * 4
+def solve():
+    with BatchAligner(pairs, alnmode=0, alntype=0, alphabet_len=4, match_score=1, mismatch_score=-1, go_score=0, ge_score=-1) as b:
+        return b.run()['score'].tolist()
+first = solve()
+import torch
+assert torch.cuda.is_available() and torch.cuda.device_count() >= 1
+t = torch.arange(8, device='cuda').sum().item()
+assert t == 28
+assert solve() == first
+maps = open('/proc/self/maps').read()
+libs = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})
+assert len(libs) == 1, libs
+print('ok', first, libs)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != 'PWLIB_HIP_RUNTIME'}
+    p = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.startswith('ok'), (p.stdout[-500:], p.stderr[-1500:])

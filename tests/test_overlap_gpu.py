@@ -172,3 +172,60 @@ def test_all_pairs_random_read_sets():
         for name in recs.dtype.names:
             if name != 'pad_':
                 assert (recs[name] == ref[name][keep]).all(), (trial, name)
+
+
+def test_all_pairs_job_every_alignment_rescored():
+    """The config-4 flow on a job of 2 000 reads of 5 kb (25x coverage of a 400 kb genome): all pairs through one index,
+    the pairs with p >= 0.8 through banded overlap alignment in chunked batches that refer to one uploaded read arena,
+    and EVERY alignment checked by the size-independent properties: re-scoring the transcript reproduces the score, every
+    M / S agrees with the letters, the path ends in the reported cell, starts on the table edge and ends on the last row
+    or column (an overlap alignment), and stays inside its band.  Recall against the known read positions."""
+    from biseqt_amd import synth, verify, _pwlib as W
+    from biseqt_amd.batch import BatchAligner, pack_reads
+    from biseqt_amd.overlap import raw_all_pairs
+    R, read_len, cov, k = 2000, 5000, 25, 16
+    rng = synth.rng_for(404)
+    G = R * read_len // cov
+    g = synth.rand_seqs(rng, 1, G)[0]
+    starts = rng.integers(0, G - read_len, R)
+    reads = [synth.mutate(rng, g[s:s + read_len], .05, .025, .025) for s in starts]
+    pairs, recs, _ = raw_all_pairs(reads, k, 4, .2, .9)
+    w = recs['w_best']
+    p = np.where(w > 0, np.exp(np.log(np.maximum(w, 1e-300)) / k), 0.0)
+    sel = np.flatnonzero(p >= .8)
+    ov = np.minimum(starts[pairs[:, 0]], starts[pairs[:, 1]]) + read_len - np.maximum(starts[pairs[:, 0]], starts[pairs[:, 1]])
+    order = np.argsort(starts); ss = starts[order]
+    true_total = int(sum(np.searchsorted(ss, ss[i] + read_len - 500, 'left') - i - 1 for i in range(R)))
+    found = int((ov[sel] > 500).sum())
+    assert found >= 0.99 * true_total and int((ov[sel] <= 0).sum()) <= 0.01 * len(sel) + 2, (found, true_total, len(sel))
+    arena, offs, lens = pack_reads(reads)
+    pidx = pairs[sel].astype(np.int64)
+    lo = np.maximum(recs['d_best'][sel].astype(np.int64) - recs['r_best'][sel], -lens[pidx[:, 1]].astype(np.int64))
+    hi = np.minimum(recs['d_best'][sel].astype(np.int64) + recs['r_best'][sel], lens[pidx[:, 0]].astype(np.int64))
+    dr = np.stack([lo, hi], axis=1)
+    cells = (hi - lo + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
+    start, n_checked, kernels = 0, 0, set()
+    while start < len(sel):
+        stop = start + max(1, int(np.searchsorted(np.cumsum(cells[start:]), 2 * 10 ** 10, 'right')))
+        with BatchAligner.from_arena(arena, offs, lens, pidx[start:stop], dr[start:stop], alnmode=W.BANDED_MODE,
+                                     alntype=W.B_OVERLAP, alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5,
+                                     ge_score=-2) as b:
+            kernels.add(b.kernel_name)
+            res = b.run()
+            txs = b.transcripts(res)
+        o_l = [reads[a] for a in pidx[start:stop, 0]]
+        m_l = [reads[c] for c in pidx[start:stop, 1]]
+        assert (res['opt_i'] >= 0).all() and ((res['status'] & 15) == W.PW_ST_TRACED).all()
+        assert verify.check_batch(o_l, m_l, res, txs, 1, -3, -5, -2, banded=True, dmins=lo[start:stop].tolist()) == []
+        for q in range(stop - start):
+            X, Y = len(o_l[q]), len(m_l[q])
+            x0, y0 = int(res['origin_idx'][q]), int(res['mutant_idx'][q])
+            ex, ey = verify.end_cell_xy(res['opt_i'][q], res['opt_j'][q], True, lo[start + q])
+            assert (x0 == 0 or y0 == 0) and (ex == X or ey == Y), q
+            ops = np.frombuffer(txs[q].encode(), np.uint8)
+            d = x0 - y0 + np.cumsum((ops == 68).astype(np.int64) - (ops == 73).astype(np.int64))
+            assert lo[start + q] <= min(d.min(), x0 - y0) and max(d.max(), x0 - y0) <= hi[start + q], q
+        n_checked += stop - start
+        start = stop
+    assert n_checked == len(sel) and n_checked > 30000
+    assert all('k_fill16' in kn for kn in kernels), kernels
