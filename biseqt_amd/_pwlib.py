@@ -113,7 +113,7 @@ SIZEOF = dict(intpair=8, alnscores=24, alnframe=32, std_alnparams=4, banded_alnp
 
 # every symbol include/pwlib.h and include/pw_batch.h declare
 EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
-           'pw_last_error', 'pw_device_count', 'pw_pool_trim', 'pw_batch_create', 'pw_batch_destroy',
+           'pw_last_error', 'pw_device_count', 'pw_device_memory', 'pw_pool_trim', 'pw_batch_create', 'pw_batch_destroy',
            'pw_batch_init_rc', 'pw_batch_band', 'pw_batch_pair_cells', 'pw_batch_cells',
            'pw_batch_algorithmic_bytes', 'pw_batch_score_type', 'pw_batch_kernel_name', 'pw_batch_upload_arena',
            'pw_batch_arena_device', 'pw_host_alloc', 'pw_host_free', 'pw_batch_upload_arena_async',
@@ -203,6 +203,7 @@ def load():
     lib.dptable_free.restype = None
     lib.pw_last_error.restype = C.c_char_p
     lib.pw_device_count.restype = C.c_int
+    lib.pw_device_memory.argtypes = [C.c_int, P(C.c_uint64), P(C.c_uint64)]
     lib.pw_pool_trim.restype = None
     lib.pw_batch_create.argtypes = [C.c_int, P(pw_scoring), C.c_int32, P(pw_pair), C.c_uint64, C.c_uint32]
     lib.pw_batch_create.restype = C.c_void_p

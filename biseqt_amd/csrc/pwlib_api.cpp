@@ -585,6 +585,15 @@ const char* pw_last_error(void) { return g_err.c_str(); }
 
 void pw_pool_trim(void) { pool_drop(-1); }
 
+int pw_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+  size_t fr = 0, tot = 0;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipMemGetInfo(&fr, &tot));
+  if (free_bytes) *free_bytes = fr;
+  if (total_bytes) *total_bytes = tot;
+  return 0;
+}
+
 int pw_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -67,6 +67,7 @@ typedef struct {
 
 const char* pw_last_error(void);
 int pw_device_count(void);
+int pw_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);   /* hipMemGetInfo of the runtime the library uses */
 
 /* Plans the batch (band clamp / feasibility per pair exactly as dptable_init), picks the kernel variants,
  * allocates every device buffer and uploads the descriptors.  The arena is `arena_bytes` long; its

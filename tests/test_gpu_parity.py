@@ -770,13 +770,12 @@ def test_buffer_pool_reuse_and_trim():
     from biseqt_amd import synth, _pwlib as W
     from biseqt_amd.batch import BatchAligner
     lib = W.load()
-    hip = ctypes.CDLL('libamdhip64.so')                  # the runtime pwlib.so is linked against
     origins, mutants = synth.pair_batch(5, 600, 1500)
     kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-150, 150), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
 
     def used():
-        free, total = ctypes.c_size_t(), ctypes.c_size_t()
-        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        free, total = ctypes.c_uint64(), ctypes.c_uint64()
+        assert lib.pw_device_memory(0, ctypes.byref(free), ctypes.byref(total)) == 0
         return (total.value - free.value) / 2.0 ** 20
 
     with BatchAligner(list(zip(origins, mutants)), **kw) as b:      # warm-up: code objects, runtime scratch
