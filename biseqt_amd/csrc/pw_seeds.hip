@@ -42,8 +42,11 @@ constexpr int kMaxMasks = 16;
 struct MaskSets { uint64_t set[kMaxMasks]; int n; };
 
 // ---- K5a ------------------------------------------------------------------------------------------------
+// Key type K: 32 bits whenever L^k (the masked key included) fits -- DNA words up to k = 15 -- which cuts the sort's
+// traffic from 12 to 8 bytes per k-mer and pass; 64 bits otherwise.
+template <typename K>
 __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ seq, int64_t n, int k, int L,
-                                                uint64_t kinv, MaskSets ms, uint64_t* __restrict__ keys,
+                                                uint64_t kinv, MaskSets ms, K* __restrict__ keys,
                                                 uint32_t* __restrict__ pos) {
   __shared__ uint8_t tile[256 + 64];
   const int64_t base = (int64_t)blockIdx.x * 256;
@@ -63,59 +66,96 @@ __global__ __launch_bounds__(256) void k_encode(const uint8_t* __restrict__ seq,
   }
   bool masked = false;
   for (int i = 0; i < ms.n; i++) masked |= lets == ms.set[i];
-  keys[p] = masked ? kinv : v;
+  keys[p] = (K)(masked ? kinv : v);
   pos[p] = (uint32_t)p;
 }
 
-__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {
+template <typename K>
+__device__ __forceinline__ int64_t lower_bound_k(const K* __restrict__ a, int64_t n, K key) {
   int64_t lo = 0, hi = n;
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
   return lo;
 }
-__device__ __forceinline__ int64_t upper_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) {
+template <typename K>
+__device__ __forceinline__ int64_t upper_bound_k(const K* __restrict__ a, int64_t n, K key) {
   int64_t lo = 0, hi = n;
   while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
   return lo;
 }
+__device__ __forceinline__ int64_t lower_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) { return lower_bound_k<uint64_t>(a, n, key); }
+__device__ __forceinline__ int64_t upper_bound_u64(const uint64_t* __restrict__ a, int64_t n, uint64_t key) { return upper_bound_k<uint64_t>(a, n, key); }
 
 // ---- K5b ------------------------------------------------------------------------------------------------
-// other = sorted keys of T (or of S itself for a self comparison)
-__global__ __launch_bounds__(256) void k_match(const uint64_t* __restrict__ ks, int64_t ns,
-                                               const uint64_t* __restrict__ other, int64_t no, uint64_t kinv,
-                                               int self, uint32_t* __restrict__ lo_out, uint64_t* __restrict__ cnt) {
+// other = sorted keys of T (or of S itself for a self comparison).  Two ways to find an element's run [lo, hi) in it:
+//   * a direct-address table tab[key] = first index of `key` in `other` (k_table_fill) when the key space is small
+//     (DNA, k <= 13: <= 256 MB of table, resident in the Infinity Cache): S is sorted too, so neighbouring threads read
+//     neighbouring table entries -- two coalesced 4-byte reads instead of 2 log2(n) dependent ones;
+//   * two binary searches otherwise.
+template <typename K>
+__global__ __launch_bounds__(256) void k_match(const K* __restrict__ ks, int64_t ns,
+                                               const K* __restrict__ other, int64_t no, uint64_t kinv,
+                                               int self, const uint32_t* __restrict__ tab, uint32_t* __restrict__ lo_out,
+                                               uint64_t* __restrict__ cnt) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= ns) return;
-  const uint64_t key = ks[e];
-  if (key >= kinv) { lo_out[e] = 0; cnt[e] = 0; return; }
-  const int64_t lo = lower_bound_u64(other, no, key);
-  const int64_t hi = upper_bound_u64(other, no, key);
+  const K key = ks[e];
+  if ((uint64_t)key >= kinv) { lo_out[e] = 0; cnt[e] = 0; return; }
+  int64_t lo, hi;
+  if (tab != nullptr) { lo = tab[(uint64_t)key]; hi = tab[(uint64_t)key + 1]; }
+  else { lo = lower_bound_k<K>(other, no, key); hi = upper_bound_k<K>(other, no, key); }
   lo_out[e] = (uint32_t)lo;
   if (!self) cnt[e] = (uint64_t)(hi - lo);
   else cnt[e] = (uint64_t)(hi - 1 - e) + (e == hi - 1 ? (uint64_t)(hi - lo) : 0ull);
 }
+// tab[q] = number of elements of `other` below q, for q = 0 .. kinv + 1: element i (the first of its run) fills the
+// keys after the previous run's key up to its own; one extra thread fills the tail.  (Used only when the keys are dense
+// enough that these gaps are short: see pw_seeds_build.)
+template <typename K>
+__global__ __launch_bounds__(256) void k_table_fill(const K* __restrict__ other, int64_t no, uint64_t kinv, uint32_t* __restrict__ tab) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > no) return;
+  const int64_t prev = i > 0 ? (int64_t)other[i - 1] : -1;
+  const int64_t cur = i < no ? (int64_t)other[i] : (int64_t)kinv + 1;
+  for (int64_t q = prev + 1; q <= cur; q++) tab[q] = (uint32_t)i;
+}
 
 // ---- K5c ------------------------------------------------------------------------------------------------
+// One thread per row, kExpRows rows per workgroup.  The element a row belongs to is found by a binary search over the
+// row offsets -- inside the window of elements that the workgroup's rows span (two searches per workgroup over the whole
+// array, then ~10 cache-resident steps per row instead of log2(n) scattered ones).
+constexpr int kExpRows = 2048;
+template <typename K>
 __global__ __launch_bounds__(256) void k_expand(const uint64_t* __restrict__ off, int64_t ns, int64_t nrows,
                                                 const uint32_t* __restrict__ ps, const uint32_t* __restrict__ po,
-                                                const uint32_t* __restrict__ lo_in, const uint64_t* __restrict__ ks,
+                                                const uint32_t* __restrict__ lo_in, const K* __restrict__ ks,
                                                 int self, int2* __restrict__ rows) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (o >= nrows) return;
-  const int64_t e = upper_bound_u64(off, ns, (uint64_t)o) - 1;      // last element whose first row is <= o
-  const int64_t r = o - (int64_t)off[e];
-  int32_t i, j;
-  if (!self) {
-    i = (int32_t)ps[e];
-    j = (int32_t)po[(int64_t)lo_in[e] + r];
-  } else {
-    // the run of e is [lo, hi): e pairs with e + 1 .. hi - 1; the last element of the run then lists (x, x)
-    const int64_t lo = lo_in[e];
-    const uint64_t key = ks[e];
-    const bool last = e + 1 >= ns || ks[e + 1] != key;
-    if (!last) { i = (int32_t)ps[e]; j = (int32_t)ps[e + 1 + r]; }
-    else { i = (int32_t)ps[lo + r]; j = i; }
+  __shared__ int64_t win[2];
+  const int64_t o0 = (int64_t)blockIdx.x * kExpRows;
+  const int64_t olast = (o0 + kExpRows < nrows ? o0 + kExpRows : nrows) - 1;
+  if (threadIdx.x == 0) win[0] = upper_bound_u64(off, ns, (uint64_t)o0) - 1;
+  if (threadIdx.x == 64) win[1] = upper_bound_u64(off, ns, (uint64_t)olast) - 1;
+  __syncthreads();
+  const int64_t e0 = win[0], nwin = win[1] - win[0] + 1;
+#pragma unroll 1
+  for (int q = 0; q < kExpRows / 256; q++) {
+    const int64_t o = o0 + q * 256 + threadIdx.x;
+    if (o >= nrows) return;
+    const int64_t e = e0 + upper_bound_u64(off + e0, nwin, (uint64_t)o) - 1;      // last element whose first row is <= o
+    const int64_t r = o - (int64_t)off[e];
+    int32_t i, j;
+    if (!self) {
+      i = (int32_t)ps[e];
+      j = (int32_t)po[(int64_t)lo_in[e] + r];
+    } else {
+      // the run of e is [lo, hi): e pairs with e + 1 .. hi - 1; the last element of the run then lists (x, x)
+      const int64_t lo = lo_in[e];
+      const K key = ks[e];
+      const bool last = e + 1 >= ns || ks[e + 1] != key;
+      if (!last) { i = (int32_t)ps[e]; j = (int32_t)ps[e + 1 + r]; }
+      else { i = (int32_t)ps[lo + r]; j = i; }
+    }
+    rows[o] = make_int2(i - j, i + j);
   }
-  rows[o] = make_int2(i - j, i + j);
 }
 
 // ---- K5d ------------------------------------------------------------------------------------------------
@@ -272,6 +312,8 @@ struct DevBuf {
 
 struct pw_seed_index {
   int device = 0, L = 0, k = 0, self = 0, bits = 0;
+  bool key32 = false;                   // L^k fits 32 bits: 4-byte keys
+  DevBuf tab;                           // direct-address table of the join (small key spaces)
   int64_t nS = 0, nT = 0, nkS = 0, nkT = 0, nrows = -1;
   uint64_t kinv = 0;
   MaskSets ms;
@@ -281,6 +323,53 @@ struct pw_seed_index {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float ms_build = 0.f;
 };
+
+template <typename K>
+static int encode_sort(pw_seed_index* x, const uint8_t* seq, int64_t n, int64_t nk, DevBuf& keys_out, DevBuf& pos_out,
+                       hipStream_t st) {
+  if (keys_out.ensure((size_t)std::max<int64_t>(nk, 1) * sizeof(K)) != 0 || pos_out.ensure((size_t)std::max<int64_t>(nk, 1) * 4) != 0) return -1;
+  if (nk <= 0) return 0;
+  if (x->keys_in.ensure((size_t)nk * sizeof(K)) != 0 || x->pos_in.ensure((size_t)nk * 4) != 0) return -1;
+  hipLaunchKernelGGL((k_encode<K>), dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, seq, n, x->k, x->L, x->kinv, x->ms,
+                     (K*)x->keys_in.p, (uint32_t*)x->pos_in.p);
+  size_t tb = 0;
+  SD_CHECK(rocprim::radix_sort_pairs(nullptr, tb, (const K*)x->keys_in.p, (K*)keys_out.p,
+                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
+                                     (unsigned)x->bits, st));
+  if (x->tmp.ensure(tb) != 0) return -1;
+  SD_CHECK(rocprim::radix_sort_pairs(x->tmp.p, tb, (const K*)x->keys_in.p, (K*)keys_out.p,
+                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
+                                     (unsigned)x->bits, st));
+  return 0;
+}
+
+// encode + sort both sequences, join them: everything of pw_seeds_build that depends on the key type
+template <typename K>
+static int build_join(pw_seed_index* x, hipStream_t st, int64_t ns, bool count_only, unsigned long long total) {
+  if (count_only) {
+    if (encode_sort<K>(x, (const uint8_t*)x->dS.p, x->nS, x->nkS, x->keys_s, x->pos_s, st) != 0) return -1;
+    if (!x->self && encode_sort<K>(x, (const uint8_t*)x->dT.p, x->nT, x->nkT, x->keys_t, x->pos_t, st) != 0) return -1;
+    if (ns <= 0) return 0;
+    const K* other = x->self ? (const K*)x->keys_s.p : (const K*)x->keys_t.p;
+    const int64_t no = x->self ? ns : x->nkT;
+    // the direct-address table pays when the key space is small and dense enough: at most 2^26 keys (256 MB of table) and on
+    // average no more than 64 keys between two consecutive elements of `other` (k_table_fill walks those gaps serially)
+    const uint32_t* tab = nullptr;
+    if (x->key32 && x->kinv <= (1ull << 26) && no > 0 && x->kinv / (uint64_t)no <= 64) {
+      if (x->tab.ensure((size_t)(x->kinv + 2) * 4) != 0) return -1;
+      hipLaunchKernelGGL((k_table_fill<K>), dim3((unsigned)((no + 256) / 256)), dim3(256), 0, st, other, no, x->kinv, (uint32_t*)x->tab.p);
+      tab = (const uint32_t*)x->tab.p;
+    }
+    hipLaunchKernelGGL((k_match<K>), dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, (const K*)x->keys_s.p, ns,
+                       other, no, x->kinv, x->self, tab, (uint32_t*)x->lo.p, (uint64_t*)x->cnt.p);
+    return 0;
+  }
+  hipLaunchKernelGGL((k_expand<K>), dim3((unsigned)((total + kExpRows - 1) / kExpRows)), dim3(256), 0, st, (const uint64_t*)x->off.p, ns,
+                     (int64_t)total, (const uint32_t*)x->pos_s.p,
+                     x->self ? (const uint32_t*)x->pos_s.p : (const uint32_t*)x->pos_t.p, (const uint32_t*)x->lo.p,
+                     (const K*)x->keys_s.p, x->self, (int2*)x->rows.p);
+  return 0;
+}
 
 extern "C" {
 
@@ -307,7 +396,11 @@ pw_seed_index* pw_seeds_create(int device, const uint8_t* S, int64_t nS, const u
   x->nkT = self_comp ? x->nkS : (nT >= wordlen ? nT - wordlen + 1 : 0);
   uint64_t kinv = 1; for (int i = 0; i < wordlen; i++) kinv *= (uint64_t)alphabet_len;
   x->kinv = kinv;
-  x->bits = 1; while ((kinv >> x->bits) != 0) x->bits++;
+  // sort width: the largest key that occurs -- L^k - 1, or the masked key L^k when mask sets are given (for DNA words
+  // without masks that is 2k bits: k = 12 sorts in three 8-bit passes instead of four)
+  const uint64_t kmax = n_masks > 0 ? kinv : (kinv > 1 ? kinv - 1 : 1);
+  x->bits = 1; while ((kmax >> x->bits) != 0) x->bits++;
+  x->key32 = kinv < 0xffffffffull;
   x->ms.n = n_masks;
   for (int i = 0; i < kMaxMasks; i++) x->ms.set[i] = i < n_masks ? mask_sets[i] : 0;
   auto fail = [&](const char* what) { if (g_err.empty()) set_err(what); pw_seeds_destroy(x); return (pw_seed_index*)nullptr; };
@@ -321,24 +414,6 @@ pw_seed_index* pw_seeds_create(int device, const uint8_t* S, int64_t nS, const u
   return x;
 }
 
-static int encode_sort(pw_seed_index* x, const uint8_t* seq, int64_t n, int64_t nk, DevBuf& keys_out, DevBuf& pos_out,
-                       hipStream_t st) {
-  if (keys_out.ensure((size_t)std::max<int64_t>(nk, 1) * 8) != 0 || pos_out.ensure((size_t)std::max<int64_t>(nk, 1) * 4) != 0) return -1;
-  if (nk <= 0) return 0;
-  if (x->keys_in.ensure((size_t)nk * 8) != 0 || x->pos_in.ensure((size_t)nk * 4) != 0) return -1;
-  hipLaunchKernelGGL(k_encode, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, seq, n, x->k, x->L, x->kinv, x->ms,
-                     (uint64_t*)x->keys_in.p, (uint32_t*)x->pos_in.p);
-  size_t tb = 0;
-  SD_CHECK(rocprim::radix_sort_pairs(nullptr, tb, (const uint64_t*)x->keys_in.p, (uint64_t*)keys_out.p,
-                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
-                                     (unsigned)x->bits, st));
-  if (x->tmp.ensure(tb) != 0) return -1;
-  SD_CHECK(rocprim::radix_sort_pairs(x->tmp.p, tb, (const uint64_t*)x->keys_in.p, (uint64_t*)keys_out.p,
-                                     (const uint32_t*)x->pos_in.p, (uint32_t*)pos_out.p, (size_t)nk, 0u,
-                                     (unsigned)x->bits, st));
-  return 0;
-}
-
 int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
   if (!x) { set_err("null index"); return -1; }
   hipStream_t st = (hipStream_t)stream;
@@ -346,17 +421,12 @@ int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
   if (max_rows <= 0) max_rows = (1ll << 31) - 1;
   x->nrows = -1; x->g_edges = -1; x->g_npts = -1;
   SD_CHECK(hipEventRecord(x->ev0, st));
-  if (encode_sort(x, (const uint8_t*)x->dS.p, x->nS, x->nkS, x->keys_s, x->pos_s, st) != 0) return -1;
-  if (!x->self && encode_sort(x, (const uint8_t*)x->dT.p, x->nT, x->nkT, x->keys_t, x->pos_t, st) != 0) return -1;
   const int64_t ns = x->nkS;
   if (x->scalar.ensure(16) != 0) return -1;
+  if (ns > 0 && (x->lo.ensure((size_t)ns * 4) != 0 || x->cnt.ensure((size_t)ns * 8) != 0 || x->off.ensure((size_t)ns * 8) != 0)) return -1;
+  if ((x->key32 ? build_join<uint32_t>(x, st, ns, true, 0) : build_join<uint64_t>(x, st, ns, true, 0)) != 0) return -1;
   unsigned long long total = 0;
   if (ns > 0) {
-    if (x->lo.ensure((size_t)ns * 4) != 0 || x->cnt.ensure((size_t)ns * 8) != 0 || x->off.ensure((size_t)ns * 8) != 0) return -1;
-    const uint64_t* other = x->self ? (const uint64_t*)x->keys_s.p : (const uint64_t*)x->keys_t.p;
-    const int64_t no = x->self ? ns : x->nkT;
-    hipLaunchKernelGGL(k_match, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, st, (const uint64_t*)x->keys_s.p, ns,
-                       other, no, x->kinv, x->self, (uint32_t*)x->lo.p, (uint64_t*)x->cnt.p);
     size_t tb = 0;
     SD_CHECK(rocprim::exclusive_scan(nullptr, tb, (const uint64_t*)x->cnt.p, (uint64_t*)x->off.p, (uint64_t)0, (size_t)ns,
                                      rocprim::plus<uint64_t>(), st));
@@ -375,12 +445,7 @@ int pw_seeds_build(pw_seed_index* x, int64_t max_rows, void* stream) {
     return -1;
   }
   if (x->rows.ensure((size_t)std::max<unsigned long long>(total, 1) * 8) != 0) return -1;
-  if (total > 0) {
-    hipLaunchKernelGGL(k_expand, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint64_t*)x->off.p, ns,
-                       (int64_t)total, (const uint32_t*)x->pos_s.p,
-                       x->self ? (const uint32_t*)x->pos_s.p : (const uint32_t*)x->pos_t.p, (const uint32_t*)x->lo.p,
-                       (const uint64_t*)x->keys_s.p, x->self, (int2*)x->rows.p);
-  }
+  if (total > 0 && (x->key32 ? build_join<uint32_t>(x, st, ns, false, total) : build_join<uint64_t>(x, st, ns, false, total)) != 0) return -1;
   SD_CHECK(hipEventRecord(x->ev1, st));
   SD_CHECK(hipEventSynchronize(x->ev1));
   SD_CHECK(hipEventElapsedTime(&x->ms_build, x->ev0, x->ev1));
@@ -432,7 +497,7 @@ int64_t pw_seeds_kmers(const pw_seed_index* xc, int which, int64_t* out, int64_t
   SD_CHECK(hipSetDevice(x->device));
   DevBuf keys, pos;
   if (keys.ensure((size_t)nk * 8) != 0 || pos.ensure((size_t)nk * 4) != 0) { keys.release(); pos.release(); return -1; }
-  hipLaunchKernelGGL(k_encode, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, nullptr,
+  hipLaunchKernelGGL((k_encode<uint64_t>), dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, nullptr,
                      (const uint8_t*)(t ? x->dT.p : x->dS.p), n, x->k, x->L, x->kinv, x->ms, (uint64_t*)keys.p, (uint32_t*)pos.p);
   std::vector<uint64_t> h((size_t)nk);
   const hipError_t e = hipMemcpy(h.data(), keys.p, (size_t)nk * 8, hipMemcpyDeviceToHost);
@@ -607,7 +672,7 @@ int pw_seeds_graph_components(const pw_seed_index* x, const uint8_t* avail, int3
 void pw_seeds_destroy(pw_seed_index* x) {
   if (!x) return;
   (void)hipSetDevice(x->device);
-  DevBuf* bufs[] = {&x->dS, &x->dT, &x->keys_in, &x->keys_s, &x->keys_t, &x->pos_in, &x->pos_s, &x->pos_t, &x->lo, &x->cnt,
+  DevBuf* bufs[] = {&x->tab, &x->dS, &x->dT, &x->keys_in, &x->keys_s, &x->keys_t, &x->pos_in, &x->pos_s, &x->pos_t, &x->lo, &x->cnt,
                     &x->off, &x->rows, &x->tmp, &x->scalar, &x->g_keys, &x->g_order, &x->g_dstart, &x->g_cnt, &x->g_off, &x->g_adj, &x->g_pts};
   for (DevBuf* b : bufs) b->release();
   if (x->ev0) (void)hipEventDestroy(x->ev0);
