@@ -83,7 +83,7 @@ template <class P, bool TRACK>
 struct StripFill {
   static constexpr int32_t NEG = -(1 << 28);       // "no such predecessor" (pw_wave.h, ScoreTraits<int32_t>)
 #ifndef PW_STRIP_ROLL_START
-#define PW_STRIP_ROLL_START 1     /* steps 0 .. 63 as a rolled loop: same speed as unrolled (measured), a third of the code */
+#define PW_STRIP_ROLL_START 0     /* 1: steps 0 .. 63 as a rolled loop (smaller code) */
 #endif
 #ifndef PW_STRIP_SUB
 #define PW_STRIP_SUB 16    /* measured: 16 -> 33.9 ms, 8 -> 35.8 ms on config 3 (one wait for memory per hand-off) */
@@ -98,12 +98,13 @@ struct StripFill {
   int32_t Hout, Uout, Lo, Hdiag, best, bestY, hlast, b0, bfirst;
   uint32_t oc, mc;
   // lane-0 feeders: lane j holds what lane 0 needs j steps from now (moved down one lane per step)
-  int32_t cH, cU; uint32_t cM;
+  int32_t cH, cU;
   // what lane 63 produced during the last steps, newest in lane 63 (moved down one lane per step) ...
   int32_t gP;                 // ... as 2 H + "the D choice is kept" (|H| < 2^27)
   int32_t vmatch, vmis, vge, vgego;   // the scores, held in vector registers (scalar registers are scarce in the loop)
-  uint64_t tE, tO;            // FIFO sub-chunks in flight (lanes 8 .. 15): even / odd sub-chunk numbers
-  uint32_t nM;                // the next block's mutant letters, loaded a block ahead (lanes 0 .. 31)
+  // the mutant letters of a block, m[32 q .. 32 q + 31], as 8 wave-uniform dwords (scalar loads: they neither occupy the
+  // vector memory counter nor a lane), this block's and the next one's; lane 0 is fed m[k - 1] at step k
+  uint32_t mwin[8], mnext[8], mlast;
   const uint8_t* mseq;
   uint64_t* fout;             // this strip's FIFO row (written from lane 63's values) or null
   const uint64_t* fin;        // the FIFO row of the strip above or null
@@ -116,13 +117,17 @@ struct StripFill {
   // MODE 0  steady: every lane holds an in-table cell that is neither the first nor the last of its row
   //      1  start of a strip (steps 0 .. 63) when its rows are all in the table and the table has more than 64 columns:
   //         lane i starts at step i; nothing else can happen (this phase is on the critical path of every hop)
-  //      2  anything (ends of rows, rows beyond the table, tiny tables)
+  //      2  anything (rows beyond the table, tiny tables): every update predicated
+  //      3  end of a strip whose rows are all in the table (blocks that hold last columns and the steps after them): the
+  //         unpredicated update again -- cells right of the last column are virtual; only the row's running best and
+  //         the capture of its last cell look at the column.  (The slowest ~100-step stretch of a strip's life sets
+  //         the pace of the whole pipeline: each strip trails the one above by that many columns.)
   template <int MODE>
-  PW_FN void step(int k, uint32_t& macc) {
+  PW_FN void step(int k, uint32_t& macc, uint32_t fM /* m[k - 1], wave-uniform */) {
     constexpr bool RAMP = MODE == 2;
     // lane 0 takes the feeders' lane-0 values; the feeders then move down a lane (what enters at lane 63 is never used)
-    const int32_t fH = cH, fU = cU; const uint32_t fM = cM;
-    cH = P::shl1(fH, fH); cU = P::shl1(fU, fU); cM = (uint32_t)P::shl1((int32_t)fM, (int32_t)fM);
+    const int32_t fH = cH, fU = cU;
+    cH = P::shl1(fH, fH); cU = P::shl1(fU, fU);
     const int32_t Hin = P::shr1(Hout, fH);
     const int32_t Uin = P::shr1(Uout, fU);
     mc = (uint32_t)P::shr1((int32_t)mc, (int32_t)fM);
@@ -137,9 +142,12 @@ struct StripFill {
       const bool ball = a.brule == BRULE_ANY || (edge && (a.brule == BRULE_EDGE || orig));
       bq = ball ? 0 : NEG;
     } else if (MODE == 1) {
-      active = y >= 0;
-      // the first cell of a row may begin an alignment on the table edge (b0 already covers "anywhere" and row 0)
-      bq = y == 0 ? bfirst : b0;
+      // Lanes that have not reached column 0 yet run the same unpredicated update on "virtual" cells: with no begin
+      // candidate (and nothing but the initial "no predecessor" values around them) their scores stay below -2^27, which
+      // every real cell treats as "no such predecessor" -- exactly what the cells left of column 0 are.  So the first
+      // 64 steps of a strip, which sit on the critical path of every hop, cost the same as steady ones.  The first real
+      // cell of a row (y == 0) may begin an alignment on the table edge (b0 already covers "anywhere" and row 0).
+      bq = y < 0 ? NEG : (y == 0 ? bfirst : b0);
     }
     // maximum in the reference's candidate order B, D, I, M (pw.c:92-103); every kept choice shares the score
     int32_t Hn = hD > hI ? hD : hI;
@@ -160,14 +168,18 @@ struct StripFill {
         const bool upd = active && Hn > best;
         best = upd ? Hn : best; bestY = upd ? y : bestY;
       }
-    } else if (MODE == 1) {
-      macc = (macc << 4) | nib;                    // (cells before a row's start are never visited by the walker)
-      Hout = active ? Hn : Hout; Uout = active ? Un : Uout; Lo = active ? Ln : Lo;
+    } else if (MODE == 3) {
+      macc = (macc << 4) | nib;
+      Hout = Hn; Uout = Un; Lo = Ln;
+      const bool real = y <= a.Y;
+      hlast = y == a.Y ? Hn : hlast;
       if (TRACK) {
-        const bool upd = active && Hn > best;
+        const bool upd = real && Hn > best;
         best = upd ? Hn : best; bestY = upd ? y : bestY;
       }
     } else {
+      // (MODE 1: the masks of virtual cells are never visited by the walker, and their scores lose against any real
+      //  cell's in the row's running best)
       macc = (macc << 4) | nib;
       Hout = Hn; Uout = Un; Lo = Ln;
       if (TRACK) {
@@ -185,26 +197,35 @@ struct StripFill {
     if (fout == nullptr) return;
     const int y = k0 + (lane - (64 - SUB)) - 63;
     if (lane >= 64 - SUB && y >= 0 && y <= a.Y) {
-      const uint64_t g = ((uint64_t)a.epoch << 32) | (uint64_t)(uint32_t)gP;
+      const uint64_t g = ((uint64_t)tag_of(y) << 32) | (uint64_t)(uint32_t)gP;
       if (cross_out) P::fifo_store(fout + y, g);
       else P::fifo_store_local(fout + y, g);
     }
   }
 
-  // FIFO sub-chunk S = columns 8 S .. 8 S + 7 of the row above, one granule per lane `first` .. `first` + 7
-  PW_FN uint64_t load_sub(int S, int first) const {
+  // A granule's tag: the solve's epoch (24 bits) and the low bits of its column.  Whatever a register or a FIFO slot held
+  // before -- a granule of an earlier solve, of another column, nothing -- fails the comparison, so a load that has not
+  // arrived yet (or was waited for with the wrong count) is noticed and fetched again; it can never pass for data.
+  PW_FN uint32_t tag_of(int y) const { return (a.epoch << 8) | ((uint32_t)y & 0xffu); }
+
+  // FIFO sub-chunk S = columns SUB S .. SUB S + SUB - 1 of the row above, one granule per lane `first` .. `first` + SUB - 1,
+  // loaded into hand-over SLOT (0 / 1: even / odd sub-chunk numbers).  The load is NOT tracked by the compiler and does
+  // not land in a register the compiler manages (P::fifo_load_async: on the device the slot is a pair of accumulation
+  // registers) -- it is waited for by hand in merge_slot.
+  template <int SLOT>
+  PW_FN void load_sub(int S, int first) const {
     const int e = SUB * S + lane - first;
-    if (!(lane >= first && lane < first + SUB && e <= a.Y)) return 0;
-    return cross_in ? P::fifo_load(fin + e) : P::fifo_load_local(fin + e);
+    if (lane >= first && lane < first + SUB && e <= a.Y) P::template fifo_load_async<SLOT>(fin + e, cross_in);
   }
-  // Waits until the granules of sub-chunk S (in `t`, lanes first ..) carry this solve's tag and puts them into the
-  // feeders of those lanes.  False if the wait was abandoned.
-  PW_FN bool merge_sub(uint64_t t, int S, int first) {
+  // Checks that the granules of sub-chunk S (in `t`, lanes first ..) carry their tags -- polling for those that do not --
+  // and puts them into the feeders of those lanes.  False if the wait was abandoned.
+  PW_FN bool merge_value(uint64_t t, int S, int first) {
     const int e = SUB * S + lane - first;
     const bool mine = lane >= first && lane < first + SUB;
     const bool need = mine && e <= a.Y;
+    const uint32_t want = tag_of(e);
     int spins = 0;
-    while (!P::all(!need || (uint32_t)(t >> 32) == a.epoch)) {
+    while (!P::all(!need || (uint32_t)(t >> 32) == want)) {
       if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
         P::flag_set(a.ctl + kStripAbort);
         return false;
@@ -218,51 +239,70 @@ struct StripFill {
     cH = mine ? h : cH; cU = mine ? u : cU;
     return true;
   }
-  PW_FN uint32_t load_letters(int q) const {        // m[k - 1] for the steps k = 32 q + lane of block q
-    const int e = kStripBlock * q + lane;
-    const int mi = e - 1 < 0 ? 0 : (e - 1 > a.Y - 1 ? (a.Y > 0 ? a.Y - 1 : 0) : e - 1);
-    return lane < kStripBlock ? (uint32_t)mseq[mi] : 0u;
+  // ... from hand-over SLOT, once at most NW younger vector memory operations are in flight (0: none)
+  template <int SLOT, int NW>
+  PW_FN bool merge_slot(int S, int first) { return merge_value(P::template wait_vm<SLOT, NW>(), S, first); }
+  PW_FN void load_letters(int q, uint32_t (&win)[8]) const {        // m[32 q .. 32 q + 31], dwords clamped to the frame
+    const int last = a.Y > 0 ? (a.Y - 1) >> 2 : 0;
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      const int idx = 8 * q + d;
+      win[d] = P::letters_dword(mseq, idx > last ? last : idx);
+    }
   }
 
   // The 8 steps of sub-chunk J of block q: first the hand-over of the FIFO data that lane 0 will need 8 steps from now
   // (loaded 16 steps ago; the load for 16 steps further on is issued right away), then the steps, then what lane 63
   // produced goes out.
-  template <int MODE, int J>
+  template <int MODE, bool COUNTED, int J>
   PW_FN bool sub_block(int q, uint32_t (&mw)[4]) {
     const int S = NSB * q + J;
     const int k0 = kStripBlock * q + SUB * J;
     if (fin != nullptr) {
-      if (J & 1) { if (!merge_sub(tE, S + 1, SUB)) return false; tE = load_sub(S + 3, SUB); }
-      else { if (!merge_sub(tO, S + 1, SUB)) return false; tO = load_sub(S + 3, SUB); }
+      // COUNTED (steady blocks well inside the strip): every hand-over issues exactly one load and, with a strip below,
+      // one store, and every block one mask store -- so the load needed now (issued two hand-overs ago) is followed by
+      // 1 load + 1 mask store (+ 2 FIFO stores) and no wait has to drain anything younger.  Elsewhere: wait for all.
+      constexpr int SLOT = (J & 1) ? 0 : 1;              // sub-chunk S + 1: odd for even J
+      bool ok;
+      if (COUNTED) ok = fout != nullptr ? merge_slot<SLOT, 4>(S + 1, SUB) : merge_slot<SLOT, 2>(S + 1, SUB);
+      else ok = merge_slot<SLOT, 0>(S + 1, SUB);
+      if (!ok) return false;
+      load_sub<SLOT>(S + 3, SUB);
     }
-    // what lane 63 produced during the previous 8 steps goes out here, BEHIND the hand-over above: the compiler waits for
-    // vmcnt(0) wherever a load result is used while a store is in flight (loads and stores share the counter), so the
-    // only memory operations in flight at that wait should be ones issued 8 steps earlier
+    // what lane 63 produced during the previous SUB steps goes out here, behind the hand-over
     flush_out(k0 - SUB);
+    if (J == NSB - 1) load_letters(q + 1, mnext);      // the next block's letters, one hand-over ahead
 #pragma unroll
     for (int h = 0; h < SUB / 8; h++) {                  // one mask dword per 8 steps
+      constexpr int g8 = 0;
+      const int hb = J * (SUB / 8) + h;                  // 8-step group within the block
+      // m[k - 1] for the 8 steps: the last letter of the previous group, then 7 letters of this one
+      const uint64_t pair = (uint64_t)mwin[2 * hb] | ((uint64_t)mwin[2 * hb + 1] << 32);
+      const uint64_t l8 = (pair << 8) | (uint64_t)mlast;
+      mlast = (uint32_t)(pair >> 56);
       uint32_t m = 0;
-      if (MODE == 2 || (MODE == 1 && PW_STRIP_ROLL_START)) {
+      if (MODE == 2 || (MODE == 1 && PW_STRIP_ROLL_START) || MODE == 3) {
 #pragma unroll 1
-        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m);
+        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m, (uint32_t)(l8 >> (8 * s)) & 0xffu);
       } else {
 #pragma unroll
-        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m);
+        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m, (uint32_t)(l8 >> (8 * s)) & 0xffu);
       }
-      mw[J * (SUB / 8) + h] = m;
+      mw[hb] = m;
+      (void)g8;
     }
     return true;
   }
-  template <int MODE>
+  template <int MODE, bool COUNTED>
   PW_FN bool block(int q) {
-    cM = nM;
-    nM = load_letters(q + 1);
+#pragma unroll
+    for (int d = 0; d < 8; d++) mwin[d] = mnext[d];
     uint32_t mw[4];
-    if (!sub_block<MODE, 0>(q, mw)) return false;
-    if (!sub_block<MODE, 1>(q, mw)) return false;
+    if (!sub_block<MODE, COUNTED, 0>(q, mw)) return false;
+    if (!sub_block<MODE, COUNTED, 1>(q, mw)) return false;
     if (NSB == 4) {
-      if (!sub_block<MODE, 2>(q, mw)) return false;
-      if (!sub_block<MODE, 3>(q, mw)) return false;
+      if (!sub_block<MODE, COUNTED, 2>(q, mw)) return false;
+      if (!sub_block<MODE, COUNTED, 3>(q, mw)) return false;
     }
     U4 v; v.x = mw[0]; v.y = mw[1]; v.z = mw[2]; v.w = mw[3];
     *(U4*)(a.masks + strip_mask_index(a.nkq, w, q, lane)) = v;
@@ -280,7 +320,7 @@ struct StripFill {
     oc = (uint32_t)oseq[oi];
     mc = 0;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
-    gP = 0; cH = NEG; cU = NEG; cM = 0; tE = 0; tO = 0;
+    gP = 0; cH = NEG; cU = NEG; mlast = 0;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
     // steady blocks hold no first-row / first-column cell except row 0 itself
     b0 = (a.brule == BRULE_ANY || (a.brule == BRULE_EDGE && x == 0)) ? 0 : NEG;
@@ -288,15 +328,15 @@ struct StripFill {
     bfirst = (a.brule == BRULE_ANY || a.brule == BRULE_EDGE || x == 0) ? 0 : NEG;
     fin = w > 0 ? a.fifo + (uint64_t)(w - 1) * (uint64_t)a.fifo_pitch : nullptr;
     fout = w + 1 < a.nstrips ? a.fifo + (uint64_t)w * (uint64_t)a.fifo_pitch : nullptr;
-    nM = load_letters(0);
+    load_letters(0, mnext);
     stamp(1);
     if (fin != nullptr) {
-      // sub-chunks 0 and 1 in ONE poll (lanes 0 .. 15, granule = lane): 0 goes straight into the feeders, 1 already sits in
-      // the lanes the first hand-over takes it from, 2 is put in flight
+      // sub-chunks 0 and 1 in ONE poll (granule = lane): once both are there, 0 goes straight into the feeders and the
+      // hand-over slots are loaded with 1 (complete by now) and 2
       const bool need = lane < 2 * SUB && lane <= a.Y;
       uint64_t t = need ? P::fifo_load(fin + lane) : 0;
       int spins = 0;
-      while (!P::all(!need || (uint32_t)(t >> 32) == a.epoch)) {
+      while (!P::all(!need || (uint32_t)(t >> 32) == tag_of(lane))) {
         if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
           P::flag_set(a.ctl + kStripAbort);
           return false;
@@ -304,8 +344,8 @@ struct StripFill {
         P::sleep();
         if (need) t = P::fifo_poll(fin + lane);
       }
-      if (!merge_sub(t, 0, 0)) return false;
-      tO = t; tE = load_sub(2, SUB);
+      if (!merge_value(t, 0, 0)) return false;
+      load_sub<1>(1, SUB); load_sub<0>(2, SUB);
     }
     stamp(2);
     for (int q = 0; q < a.nkq; q++) {
@@ -314,10 +354,18 @@ struct StripFill {
       if (q == 3) stamp(4);
       // steady: every lane holds an in-table cell on every step of the block and none its first or last one
       const bool steady = k0 >= 63 && k0 + kStripBlock - 1 < a.Y;
-      const bool starting = k0 < 64 && a.Y > 64 && 64 * w + 63 <= a.X;
-      if (steady) { if (!block<0>(q)) return false; }
-      else if (starting) { if (!block<1>(q)) return false; }
-      else { if (!block<2>(q)) return false; }
+      const bool whole = a.Y > 64 && 64 * w + 63 <= a.X;           // every row of the strip is in the table
+      const bool starting = k0 < 64 && whole;
+      const bool ending = k0 >= 64 && whole;
+      // hand-over waits may count memory operations only where every hand-over in their window issues the same ones:
+      // from block 3 on (the FIFO stores of this strip begin with the flush at k = 64) up to a few blocks before the last
+      // columns (loads still issued), and never while clock stamps are being written
+      const bool counted = steady && q >= 3 && k0 + 4 * kStripBlock <= a.Y && a.stamps == nullptr;
+      if (steady && counted) { if (!block<0, true>(q)) return false; }
+      else if (steady) { if (!block<0, false>(q)) return false; }
+      else if (starting) { if (!block<1, false>(q)) return false; }
+      else if (ending) { if (!block<3, false>(q)) return false; }
+      else { if (!block<2, false>(q)) return false; }
     }
     flush_out(kStripBlock * a.nkq - SUB);      // the last 8 steps' cells (columns <= Y only)
     stamp(5);

@@ -42,6 +42,35 @@ struct DevPS {
   PW_FN static uint64_t fifo_load_local(const uint64_t* p) { return __builtin_nontemporal_load((const g_u64*)p); }
   // (NOT volatile: a volatile store is emitted write-through and followed by s_waitcnt vmcnt(0))
   PW_FN static void fifo_store_local(uint64_t* p, uint64_t v) { *(g_u64*)p = v; }
+  // The hand-over loads of the steady loop.  On gfx9-family targets loads and stores share vmcnt and the compiler waits for
+  // vmcnt(0) as soon as both kinds are in flight -- here a full drain of the mask / FIFO stores (~1.2 us) at every
+  // hand-over.  So these loads are issued by an asm statement the compiler does not count, and waited for by hand with a
+  // count (wait_vm<SLOT, N>: at most N younger vector memory operations may remain in flight).  Their destination must
+  // stay untouched until the data arrives, which no register the compiler allocates can promise (a copy frees the
+  // original, the late data then lands in whatever lives there next): they go to ACCUMULATION registers a[2 SLOT],
+  // a[2 SLOT + 1], which this kernel uses for nothing else (gfx950: unified VGPR / AGPR file; vector memory instructions
+  // can target them).  The pair is zeroed first, so "not arrived yet" reads as a granule without a tag.
+  template <int SLOT> PW_FN static void fifo_load_async(const uint64_t* p, bool cross) {
+    static_assert(SLOT == 0 || SLOT == 1, "two hand-over slots");
+    if (SLOT == 0) {
+      if (cross) asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tglobal_load_dwordx2 a[0:1], %0, off sc1" :: "v"(p) : "memory", "a0", "a1");
+      else asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tglobal_load_dwordx2 a[0:1], %0, off nt" :: "v"(p) : "memory", "a0", "a1");
+    } else {
+      if (cross) asm volatile("v_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tglobal_load_dwordx2 a[2:3], %0, off sc1" :: "v"(p) : "memory", "a2", "a3");
+      else asm volatile("v_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tglobal_load_dwordx2 a[2:3], %0, off nt" :: "v"(p) : "memory", "a2", "a3");
+    }
+  }
+  template <int SLOT, int N> PW_FN static uint64_t wait_vm() {
+    uint32_t lo, hi;
+    if (SLOT == 0) asm volatile("s_waitcnt vmcnt(%2)\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1" : "=v"(lo), "=v"(hi) : "n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%2)\n\tv_accvgpr_read_b32 %0, a2\n\tv_accvgpr_read_b32 %1, a3" : "=v"(lo), "=v"(hi) : "n"(N) : "memory");
+    return ((uint64_t)hi << 32) | lo;
+  }
+  // mutant letters: scalar loads from the constant address space (lgkmcnt, not vmcnt; the frame is 4-byte aligned)
+  PW_FN static uint32_t letters_dword(const uint8_t* m, int idx) {
+    typedef const __attribute__((address_space(4))) uint32_t c_u32;
+    return ((c_u32*)m)[idx];
+  }
   // Loads of the waiting loops: issued and waited for inside one asm statement, so that the compiler's count of
   // outstanding memory operations -- which lets the fast path wait for exactly the load it needs (vmcnt(N)) -- never
   // meets a load inside a loop of unknown length (that would turn every wait into vmcnt(0)).

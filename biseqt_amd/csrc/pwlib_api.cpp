@@ -498,8 +498,8 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
     a.X = d.X; a.Y = d.Y;
     a.nstrips = (d.X + 1 + 63) / 64; a.nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
     a.fifo_pitch = (d.Y + 1 + 63) / 64 * 64;
-    uint32_t e = g_strip_epoch.fetch_add(1);
-    if (e == 0) e = g_strip_epoch.fetch_add(1);
+    uint32_t e = g_strip_epoch.fetch_add(1) & 0xffffffu;          // 24 bits: the tag's other 8 are the column's low bits
+    if (e == 0) e = g_strip_epoch.fetch_add(1) & 0xffffffu;
     a.epoch = e;
     a.brule = b->brule; a.endrule = b->endrule;
     a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);

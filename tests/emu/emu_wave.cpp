@@ -99,6 +99,12 @@ struct EmuPS : EmuP {
   static uint64_t fifo_load(const uint64_t* p) { return *p; }
   static uint64_t fifo_poll(const uint64_t* p) { return *p; }
   static uint64_t fifo_load_local(const uint64_t* p) { return *p; }
+  static uint64_t* slot(int s) { static uint64_t slots[2][Emu::N]; return &slots[s][Emu::self->cur]; }
+  template <int SLOT> static void fifo_load_async(const uint64_t* p, bool) { *slot(SLOT) = *p; }
+  template <int SLOT, int N> static uint64_t wait_vm() { return *slot(SLOT); }
+  static uint32_t letters_dword(const uint8_t* m, int idx) {
+    return (uint32_t)m[4 * idx] | ((uint32_t)m[4 * idx + 1] << 8) | ((uint32_t)m[4 * idx + 2] << 16) | ((uint32_t)m[4 * idx + 3] << 24);
+  }
   static uint32_t flag_poll(const uint32_t* p) { return *p; }
   static void fifo_store(uint64_t* p, uint64_t v) { *p = v; }
   static void fifo_store_local(uint64_t* p, uint64_t v) { *p = v; }
@@ -188,7 +194,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   if ((int64_t)64 * bk < pl.ndiag) return -3;
   // arena: origin at 0, mutant after it, both padded
   const int opad = ((X > 0 ? X : 1) + 31) / 16 * 16;
-  const int mpad = ((Y > 0 ? Y : 1) + 31) / 16 * 16;
+  const int mpad = ((Y > 0 ? Y : 1) + 31) / 16 * 16 + 16;
   std::vector<uint8_t> arena(opad + mpad, 0);
   for (int i = 0; i < X; i++) arena[i] = (uint8_t)origin[i];
   for (int i = 0; i < Y; i++) arena[opad + i] = (uint8_t)mutant[i];
@@ -277,7 +283,7 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
   a.nkq = (Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
   a.fifo_pitch = (Y + 1 + 63) / 64 * 64;
   std::vector<uint64_t> fifo((size_t)a.nstrips * a.fifo_pitch, 0x00000000deadbeefull);   // stale granules of "earlier solves"
-  for (size_t i = 0; i < fifo.size(); i += 3) fifo[i] = ((uint64_t)(epoch - 1) << 32) | 12345u;
+  for (size_t i = 0; i < fifo.size(); i += 3) fifo[i] = ((uint64_t)(((epoch - 1) << 8) | (i & 0xffu)) << 32) | 12345u;
   std::vector<uint32_t> masks((size_t)a.nstrips * a.nkq * 64 * 4, 0xdeadbeefu);
   std::vector<pw::StripBest> sbest(a.nstrips);
   uint32_t ctl[16] = {0};
