@@ -281,7 +281,7 @@ struct StripFill {
       const uint64_t l8 = (pair << 8) | (uint64_t)mlast;
       mlast = (uint32_t)(pair >> 56);
       uint32_t m = 0;
-      if (MODE == 2 || (MODE == 1 && PW_STRIP_ROLL_START) || MODE == 3) {
+      if (MODE == 2 || ((MODE == 1 || MODE == 3) && PW_STRIP_ROLL_START)) {
 #pragma unroll 1
         for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m, (uint32_t)(l8 >> (8 * s)) & 0xffu);
       } else {

@@ -330,7 +330,11 @@ int batch_build(pw_batch* b) {
     bool tiled = false;
     const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
                           !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED)) && !env_int("PWLIB_NO_STRIP", 0);
-    if (strip_ok && ((b->flags & PW_FLAG_FORCE_STRIP) || d.ndiag > 2048 * pw::kMaxWavesPerPair)) {
+    // ... always for tables wider than a workgroup holds; and for the few-pairs case (strip pairs run one after another,
+    // each with the whole chip: 2 kb x 2 kb in 0.6 ms against 13.6 ms for one workgroup of 32-diagonal lanes, 8 kb x 8 kb
+    // 2.3 ms against 89 ms -- tests/micro/mid_pairs.py), when the table spans at least two strips
+    const bool few = latency_mode && ((nsolv <= 4 && d.X >= 127) || (nsolv <= 16 && d.ndiag >= 4096));
+    if (strip_ok && ((b->flags & PW_FLAG_FORCE_STRIP) || d.ndiag > 2048 * pw::kMaxWavesPerPair || (few && !env_int("PWLIB_NO_SMALL_STRIP", 0)))) {
       // one pair wider than a workgroup, integer scores, simple scoring: rows in strips of 64, a pipeline of wavefronts
       const int nstrips = (d.X + 1 + 63) / 64, nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
       d.layout = 1; d.bk = 0; d.nl = 64;

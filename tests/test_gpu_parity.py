@@ -651,8 +651,11 @@ def test_wide_pairs_single_wavefront_and_latency_mode(oracle, latency_mode, monk
             res = b.run()
             txs = b.transcripts(res)
         ndiag = (band[1] - band[0] + 1) if band is not None else len(o) + len(m) + 1
+        strip_ok = mode == 0 and not flags            # standard mode, integer scores, simple scoring: the strip pipeline
         if latency_mode == '0':
-            assert 'k_fill_mw' not in name, name
+            assert 'k_fill_mw' not in name and 'strip' not in name, name
+        elif strip_ok:
+            assert 'k_fill_strip' in name, (name, ndiag)     # a couple of pairs: row strips, one pair after another
         elif ndiag > 1024:                       # (up to 64 x 12 diagonals the packed one-wavefront kernel may still win)
             assert 'k_fill_mw' in name, (name, ndiag)
         r = oracle.solve(o, m, **okw)
