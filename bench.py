@@ -193,6 +193,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
+    # stdout carries exactly one JSON line: libraries that print banners there (RCCL's version block at communicator
+    # set-up) are sent to stderr for the rest of the run, the line goes to the original descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29513')
@@ -433,7 +438,8 @@ def main():
             line['variants'] = variants
         if cpu is not None:
             line['cpu_baseline'] = cpu
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + '\n').encode())
     for b in batches:
         b.close()
     if use_dist:
