@@ -85,18 +85,27 @@ struct StripFill {
 #ifndef PW_STRIP_ROLL_START
 #define PW_STRIP_ROLL_START 0     /* 1: steps 0 .. 63 as a rolled loop (smaller code) */
 #endif
+#ifndef PW_STRIP_MID
+#define PW_STRIP_MID 0     /* 1: hand-over in the middle of a sub-chunk (A/B: slower) */
+#endif
 #ifndef PW_STRIP_SUB
 #define PW_STRIP_SUB 16    /* measured: 16 -> 33.9 ms, 8 -> 35.8 ms on config 3 (one wait for memory per hand-off) */
 #endif
   static constexpr int SUB = PW_STRIP_SUB;         // FIFO granules per hand-off (one store / one load of SUB lanes)
   static constexpr int NSB = kStripBlock / SUB;    // hand-offs per block
-  static_assert(SUB == 8 || SUB == 16, "hand-off size");
+  static_assert(SUB == 16, "hand-off size (the hand-over sits in the middle of a sub-chunk)");
   const StripParams& a;
   int lane, w, x;
   // per lane: the cell computed last (H, what it offers downwards / rightwards), the diagonal predecessor of the
   // next cell, the row's letter and the mutant letter that travels with the wavefront
   int32_t Hout, Uout, Lo, Hdiag, best, bestY, hlast, b0, bfirst;
-  uint32_t oc, mc;
+  int32_t kbest;              // steady blocks: the row's running best as a key, 32 * H + (31 - step within the block)
+  int32_t bqv;                // MODE 4: the begin candidate of this lane's current cell (moves down one lane per step)
+  uint32_t oc;
+  // the mutant letters this lane meets: lane i needs m[k - 1 - i] at step k, so over the 4 steps of a group (k = 4 g ..
+  // 4 g + 3) the 4 bytes that begin at byte 3 - (i mod 4) of the dword pair m32[g - 1 - i / 4], m32[g - i / 4] -- the
+  // byte offset is fixed per lane, and the dword a lane needs next is the one the lane 4 below it needed a group ago
+  uint32_t w0, w1, wpend, wshift, wfrom;
   // lane-0 feeders: lane j holds what lane 0 needs j steps from now (moved down one lane per step)
   int32_t cH, cU;
   // what lane 63 produced during the last steps, newest in lane 63 (moved down one lane per step) ...
@@ -104,7 +113,11 @@ struct StripFill {
   int32_t vmatch, vmis, vge, vgego;   // the scores, held in vector registers (scalar registers are scarce in the loop)
   // the mutant letters of a block, m[32 q .. 32 q + 31], as 8 wave-uniform dwords (scalar loads: they neither occupy the
   // vector memory counter nor a lane), this block's and the next one's; lane 0 is fed m[k - 1] at step k
-  uint32_t mwin[8], mnext[8], mlast;
+  uint32_t mwin[8], mnext[8];
+  // the tie masks of the block just finished; they are stored behind the NEXT hand-over, so that a wait that has to drain
+  // this wavefront's stores (a poll, the uncounted waits) finds them a whole sub-block old
+  uint32_t mprev[4];
+  int mprev_q;
   const uint8_t* mseq;
   uint64_t* fout;             // this strip's FIFO row (written from lane 63's values) or null
   const uint64_t* fin;        // the FIFO row of the strip above or null
@@ -123,14 +136,14 @@ struct StripFill {
   //         the capture of its last cell look at the column.  (The slowest ~100-step stretch of a strip's life sets
   //         the pace of the whole pipeline: each strip trails the one above by that many columns.)
   template <int MODE>
-  PW_FN void step(int k, uint32_t& macc, uint32_t fM /* m[k - 1], wave-uniform */) {
+  PW_FN void step(int k, int j /* step within the block */, uint32_t& macc, uint32_t mc /* this lane's mutant letter */) {
     constexpr bool RAMP = MODE == 2;
-    // lane 0 takes the feeders' lane-0 values; the feeders then move down a lane (what enters at lane 63 is never used)
+    // lane 0 takes the feeders' lane-0 values; the feeders then move down a lane (what enters at lane 63 is never used:
+    // zero fill, so the shifted copy does not depend on the old one and the old register can take the shift below)
     const int32_t fH = cH, fU = cU;
-    cH = P::shl1(fH, fH); cU = P::shl1(fU, fU);
+    cH = P::shl1z(fH); cU = P::shl1z(fU);
     const int32_t Hin = P::shr1(Hout, fH);
     const int32_t Uin = P::shr1(Uout, fU);
-    mc = (uint32_t)P::shr1((int32_t)mc, (int32_t)fM);
     const int y = k - lane;
     const int32_t hD = Uin, hI = Lo;
     const int32_t hM = Hdiag + (oc == mc ? vmatch : vmis);
@@ -141,6 +154,10 @@ struct StripFill {
       const bool edge = x == 0 || y == 0, orig = x == 0 && y == 0;
       const bool ball = a.brule == BRULE_ANY || (edge && (a.brule == BRULE_EDGE || orig));
       bq = ball ? 0 : NEG;
+    } else if (MODE == 4) {
+      // MODE 1 for strips below the first, where the begin candidates are the same in every row: NEG left of column 0,
+      // `bfirst` in column 0, `b0` after it -- a sequence that simply moves down one lane per step
+      bq = bqv = P::shr1(bqv, k == 0 ? bfirst : b0);
     } else if (MODE == 1) {
       // Lanes that have not reached column 0 yet run the same unpredicated update on "virtual" cells: with no begin
       // candidate (and nothing but the initial "no predecessor" values around them) their scores stay below -2^27, which
@@ -182,25 +199,33 @@ struct StripFill {
       //  cell's in the row's running best)
       macc = (macc << 4) | nib;
       Hout = Hn; Uout = Un; Lo = Ln;
-      if (TRACK) {
+      if (TRACK && (MODE == 0 || MODE == 4)) {
+        // every cell is a real one here (|H| < 2^25): one shift-or and one max instead of compare, two selects and the
+        // column; block<0> turns the key back into (best, bestY).  (MODE 4: virtual cells, far below, are clamped.)
+        const int32_t floor25 = -(1 << 25);
+        const int32_t Hk = MODE == 4 ? (Hn > floor25 ? Hn : floor25) : Hn;
+        const int32_t key = (int32_t)(((uint32_t)Hk << 5) | (uint32_t)(31 - j));
+        kbest = key > kbest ? key : kbest;
+      } else if (TRACK) {
         const bool upd = Hn > best;
         best = upd ? Hn : best; bestY = upd ? y : bestY;
       }
     }
     // what the strip below will read: lane 63's cells, collected across the lanes (lane 63 has no source and keeps
     // its own new value; a cell outside the table is dropped when the granules are written)
-    gP = P::shl1(gP, Hn + Hn + (bD ? 1 : 0));
+    gP = P::shl1(gP, P::twice_plus(Hn, bD));
   }
 
   // After the SUB steps k0 .. k0 + SUB - 1: lane 64 - SUB + j holds lane 63's cell of step k0 + j, column y = k0 + j - 63.
-  PW_FN void flush_out(int k0) {
-    if (fout == nullptr) return;
+  PW_FN bool flush_out(int k0) {             // true if a store was issued (wave-uniform)
+    if (fout == nullptr || k0 + SUB - 64 < 0 || k0 - 63 > a.Y) return false;
     const int y = k0 + (lane - (64 - SUB)) - 63;
     if (lane >= 64 - SUB && y >= 0 && y <= a.Y) {
       const uint64_t g = ((uint64_t)tag_of(y) << 32) | (uint64_t)(uint32_t)gP;
       if (cross_out) P::fifo_store(fout + y, g);
       else P::fifo_store_local(fout + y, g);
     }
+    return true;
   }
 
   // A granule's tag: the solve's epoch (24 bits) and the low bits of its column.  Whatever a register or a FIFO slot held
@@ -211,7 +236,7 @@ struct StripFill {
   // FIFO sub-chunk S = columns SUB S .. SUB S + SUB - 1 of the row above, one granule per lane `first` .. `first` + SUB - 1,
   // loaded into hand-over SLOT (0 / 1: even / odd sub-chunk numbers).  The load is NOT tracked by the compiler and does
   // not land in a register the compiler manages (P::fifo_load_async: on the device the slot is a pair of accumulation
-  // registers) -- it is waited for by hand in merge_slot.
+  // registers) -- it is waited for by hand (P::wait_vm) in sub_block.
   template <int SLOT>
   PW_FN void load_sub(int S, int first) const {
     const int e = SUB * S + lane - first;
@@ -219,9 +244,9 @@ struct StripFill {
   }
   // Checks that the granules of sub-chunk S (in `t`, lanes first ..) carry their tags -- polling for those that do not --
   // and puts them into the feeders of those lanes.  False if the wait was abandoned.
-  PW_FN bool merge_value(uint64_t t, int S, int first) {
+  PW_FN bool merge_value(uint64_t t, int S, int first, int count = SUB) {
     const int e = SUB * S + lane - first;
-    const bool mine = lane >= first && lane < first + SUB;
+    const bool mine = lane >= first && lane < first + count;
     const bool need = mine && e <= a.Y;
     const uint32_t want = tag_of(e);
     int spins = 0;
@@ -231,7 +256,7 @@ struct StripFill {
         return false;
       }
       P::sleep();
-      if (need) t = P::fifo_poll(fin + e);
+      if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + e) : P::fifo_poll_local(fin + e);
     }
     const int32_t pk = (int32_t)(uint32_t)t;
     const int32_t h = need ? (pk >> 1) : NEG;
@@ -239,11 +264,15 @@ struct StripFill {
     cH = mine ? h : cH; cU = mine ? u : cU;
     return true;
   }
-  // ... from hand-over SLOT, once at most NW younger vector memory operations are in flight (0: none)
-  template <int SLOT, int NW>
-  PW_FN bool merge_slot(int S, int first) { return merge_value(P::template wait_vm<SLOT, NW>(), S, first); }
+  PW_FN void store_masks() {
+    if (mprev_q < 0) return;
+    U4 v; v.x = mprev[0]; v.y = mprev[1]; v.z = mprev[2]; v.w = mprev[3];
+    *(U4*)(a.masks + strip_mask_index(a.nkq, w, mprev_q, lane)) = v;
+    mprev_q = -1;
+  }
   PW_FN void load_letters(int q, uint32_t (&win)[8]) const {        // m[32 q .. 32 q + 31], dwords clamped to the frame
     const int last = a.Y > 0 ? (a.Y - 1) >> 2 : 0;
+    if (8 * q + 7 <= last) { P::letters_x8(mseq, 8 * q, win); return; }      // one 32-byte scalar load
 #pragma unroll
     for (int d = 0; d < 8; d++) {
       const int idx = 8 * q + d;
@@ -251,61 +280,107 @@ struct StripFill {
     }
   }
 
-  // The 8 steps of sub-chunk J of block q: first the hand-over of the FIFO data that lane 0 will need 8 steps from now
-  // (loaded 16 steps ago; the load for 16 steps further on is issued right away), then the steps, then what lane 63
-  // produced goes out.
-  template <int MODE, bool COUNTED, int J>
+  // Start of the 4-step group whose first step is k = 4 g; `fresh` = m32[g] (wave-uniform).  Returns the lane's 4 letters.
+  PW_FN uint32_t letters_group(uint32_t fresh) {
+    const uint32_t nw = lane < 4 ? fresh : wpend;
+    w0 = w1; w1 = nw;
+    wpend = P::lane_from(wfrom, w1);          // for the next group: what the lane 4 below holds now
+    P::issue_here();                          // (issued now, so that its latency is over by then)
+    return P::alignbyte(w1, w0, wshift);
+  }
+
+  // The SUB steps of sub-chunk J of block q.  In front of them what lane 63 produced during the previous SUB steps goes
+  // out.  In their MIDDLE the hand-over: the granules lane 0 will need from step SUB (S + 1) on (sub-chunk S + 1) go from
+  // their hand-over slot into the feeders (lanes SUB/2 ..), and the load of sub-chunk S + 2 is issued -- late enough to
+  // find the granules written when this strip trails the one above by the ~108 columns it starts with (so the start of a
+  // strip, which sets the pace of the whole pipeline, does not have to poll), and SUB steps ahead of its own hand-over.
+  // Right behind the load goes the previous block's mask store.  The wait for a slot counts out what was issued after its
+  // load -- that mask store and the FIFO store in front of this sub-chunk (vmcnt(0 .. 2)); everything older has had SUB
+  // steps to complete.  (On gfx9-family targets loads and stores share one counter, so a wait for "everything" drains the
+  // stores: ~1.2 us, once per hand-over, was the cost of not counting.)
+  template <int MODE, int J>
   PW_FN bool sub_block(int q, uint32_t (&mw)[4]) {
     const int S = NSB * q + J;
     const int k0 = kStripBlock * q + SUB * J;
-    if (fin != nullptr) {
-      // COUNTED (steady blocks well inside the strip): every hand-over issues exactly one load and, with a strip below,
-      // one store, and every block one mask store -- so the load needed now (issued two hand-overs ago) is followed by
-      // 1 load + 1 mask store (+ 2 FIFO stores) and no wait has to drain anything younger.  Elsewhere: wait for all.
-      constexpr int SLOT = (J & 1) ? 0 : 1;              // sub-chunk S + 1: odd for even J
-      bool ok;
-      if (COUNTED) ok = fout != nullptr ? merge_slot<SLOT, 4>(S + 1, SUB) : merge_slot<SLOT, 2>(S + 1, SUB);
-      else ok = merge_slot<SLOT, 0>(S + 1, SUB);
-      if (!ok) return false;
-      load_sub<SLOT>(S + 3, SUB);
+    constexpr int SLOT = (J & 1) ? 0 : 1;                // sub-chunk S + 1: odd for even J
+    if (fin == nullptr) {
+      // no row above: "no predecessor" keeps entering the feeders where the granules would (the shift fills with zeros)
+      const bool mine = lane >= SUB && lane < 2 * SUB;
+      cH = mine ? NEG : cH; cU = mine ? NEG : cU;
     }
-    // what lane 63 produced during the previous SUB steps goes out here, behind the hand-over
-    flush_out(k0 - SUB);
-    if (J == NSB - 1) load_letters(q + 1, mnext);      // the next block's letters, one hand-over ahead
+#if !PW_STRIP_MID
+    else {
+      // J odd: the mask store of block q - 1 was issued behind the load (there is none in front of block 0)
+      const uint64_t t = ((J & 1) && q > 0) ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>();
+      if (!merge_value(t, S + 1, SUB)) return false;
+    }
+#endif
+    const bool flushed = flush_out(k0 - SUB);
+    (void)flushed;
 #pragma unroll
     for (int h = 0; h < SUB / 8; h++) {                  // one mask dword per 8 steps
-      constexpr int g8 = 0;
       const int hb = J * (SUB / 8) + h;                  // 8-step group within the block
-      // m[k - 1] for the 8 steps: the last letter of the previous group, then 7 letters of this one
-      const uint64_t pair = (uint64_t)mwin[2 * hb] | ((uint64_t)mwin[2 * hb + 1] << 32);
-      const uint64_t l8 = (pair << 8) | (uint64_t)mlast;
-      mlast = (uint32_t)(pair >> 56);
+      if (h == SUB / 16) {
+#if !PW_STRIP_MID
+        if (fin != nullptr) load_sub<1 - SLOT>(S + 2, SUB);
+#else
+        if (fin != nullptr) {
+          if (S >= 1) {                                  // (run() put sub-chunks 0 and 1 into the feeders)
+            const int younger = (((J & 1) && q > 0) ? 1 : 0) + (flushed ? 1 : 0);
+            const uint64_t t = younger == 2 ? P::template wait_vm<SLOT, 2>()
+                                            : (younger == 1 ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>());
+            if (!merge_value(t, S + 1, SUB / 2)) return false;
+          }
+          load_sub<1 - SLOT>(S + 2, SUB / 2);
+        }
+#endif
+        if (J == 0) store_masks();
+      }
       uint32_t m = 0;
-      if (MODE == 2 || ((MODE == 1 || MODE == 3) && PW_STRIP_ROLL_START)) {
-#pragma unroll 1
-        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m, (uint32_t)(l8 >> (8 * s)) & 0xffu);
-      } else {
 #pragma unroll
-        for (int s = 0; s < 8; s++) step<MODE>(k0 + 8 * h + s, m, (uint32_t)(l8 >> (8 * s)) & 0xffu);
+      for (int g2 = 0; g2 < 2; g2++) {
+        const uint32_t l4 = letters_group(mwin[2 * hb + g2]);
+        // the next block's letters: scalar loads share lgkmcnt with the lane exchange above, so they are issued right
+        // behind one group's wait and have the 4 steps to the next one to arrive
+        if (J == NSB - 1 && h == 0 && g2 == 0) load_letters(q + 1, mnext);
+        const int j0 = 8 * hb + 4 * g2;                    // step within the block
+        if (MODE == 2 || ((MODE == 1 || MODE == 3 || MODE == 4) && PW_STRIP_ROLL_START)) {
+#pragma unroll 1
+          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, P::byte_of(l4, s));
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, P::byte_of(l4, s));
+        }
       }
       mw[hb] = m;
-      (void)g8;
     }
     return true;
   }
-  template <int MODE, bool COUNTED>
+  template <int MODE>
   PW_FN bool block(int q) {
 #pragma unroll
     for (int d = 0; d < 8; d++) mwin[d] = mnext[d];
     uint32_t mw[4];
-    if (!sub_block<MODE, COUNTED, 0>(q, mw)) return false;
-    if (!sub_block<MODE, COUNTED, 1>(q, mw)) return false;
-    if (NSB == 4) {
-      if (!sub_block<MODE, COUNTED, 2>(q, mw)) return false;
-      if (!sub_block<MODE, COUNTED, 3>(q, mw)) return false;
+    int32_t kb0 = 0;
+    if (TRACK && (MODE == 0 || MODE == 4)) {
+      const int32_t floor25 = -(1 << 25);
+      kb0 = (int32_t)(((uint32_t)(best > floor25 ? best : floor25) << 5) | 31u);   // an equal score later in the row loses
+      kbest = kb0;
     }
-    U4 v; v.x = mw[0]; v.y = mw[1]; v.z = mw[2]; v.w = mw[3];
-    *(U4*)(a.masks + strip_mask_index(a.nkq, w, q, lane)) = v;
+    if (!sub_block<MODE, 0>(q, mw)) return false;
+    if (!sub_block<MODE, 1>(q, mw)) return false;
+    if (NSB == 4) {
+      if (!sub_block<MODE, 2>(q, mw)) return false;
+      if (!sub_block<MODE, 3>(q, mw)) return false;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; d++) mprev[d] = mw[d];
+    mprev_q = q;
+    if (TRACK && (MODE == 0 || MODE == 4)) {
+      const bool ch = kbest != kb0;
+      best = ch ? (kbest >> 5) : best;
+      bestY = ch ? kStripBlock * q + (31 - (kbest & 31)) - lane : bestY;
+    }
     return true;
   }
 
@@ -317,10 +392,11 @@ struct StripFill {
     const uint8_t* oseq = a.arena + a.o_off;
     mseq = a.arena + a.m_off;
     const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
-    oc = (uint32_t)oseq[oi];
-    mc = 0;
+    oc = (uint32_t)P::in_vgpr((int32_t)oseq[oi]);      // opaque: a compare known to be 8 bits wide is not folded into a byte select
+    w0 = 0; w1 = 0; wpend = 0; wshift = 3u - ((uint32_t)lane & 3u); wfrom = (uint32_t)((lane - 4) & 63);
+    kbest = 0; mprev_q = -1; bqv = NEG;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
-    gP = 0; cH = NEG; cU = NEG; mlast = 0;
+    gP = 0; cH = NEG; cU = NEG;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
     // steady blocks hold no first-row / first-column cell except row 0 itself
     b0 = (a.brule == BRULE_ANY || (a.brule == BRULE_EDGE && x == 0)) ? 0 : NEG;
@@ -331,8 +407,7 @@ struct StripFill {
     load_letters(0, mnext);
     stamp(1);
     if (fin != nullptr) {
-      // sub-chunks 0 and 1 in ONE poll (granule = lane): once both are there, 0 goes straight into the feeders and the
-      // hand-over slots are loaded with 1 (complete by now) and 2
+      // sub-chunks 0 and 1 in ONE poll (granule = lane): once both are there they go straight into the feeders
       const bool need = lane < 2 * SUB && lane <= a.Y;
       uint64_t t = need ? P::fifo_load(fin + lane) : 0;
       int spins = 0;
@@ -342,32 +417,34 @@ struct StripFill {
           return false;
         }
         P::sleep();
-        if (need) t = P::fifo_poll(fin + lane);
+        if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + lane) : P::fifo_poll_local(fin + lane);
       }
+#if PW_STRIP_MID
+      if (!merge_value(t, 0, 0, 2 * SUB)) return false;
+#else
       if (!merge_value(t, 0, 0)) return false;
-      load_sub<1>(1, SUB); load_sub<0>(2, SUB);
+      load_sub<1>(1, SUB);
+#endif
     }
     stamp(2);
     for (int q = 0; q < a.nkq; q++) {
       const int k0 = kStripBlock * q;
       if (q == 2) stamp(3);
       if (q == 3) stamp(4);
+      if (k0 + kStripBlock - 1 >= a.Y && k0 - kStripBlock + kStripBlock - 1 < a.Y) stamp(6);     // first block past the steady ones
       // steady: every lane holds an in-table cell on every step of the block and none its first or last one
       const bool steady = k0 >= 63 && k0 + kStripBlock - 1 < a.Y;
       const bool whole = a.Y > 64 && 64 * w + 63 <= a.X;           // every row of the strip is in the table
       const bool starting = k0 < 64 && whole;
       const bool ending = k0 >= 64 && whole;
-      // hand-over waits may count memory operations only where every hand-over in their window issues the same ones:
-      // from block 3 on (the FIFO stores of this strip begin with the flush at k = 64) up to a few blocks before the last
-      // columns (loads still issued), and never while clock stamps are being written
-      const bool counted = steady && q >= 3 && k0 + 4 * kStripBlock <= a.Y && a.stamps == nullptr;
-      if (steady && counted) { if (!block<0, true>(q)) return false; }
-      else if (steady) { if (!block<0, false>(q)) return false; }
-      else if (starting) { if (!block<1, false>(q)) return false; }
-      else if (ending) { if (!block<3, false>(q)) return false; }
-      else { if (!block<2, false>(q)) return false; }
+      if (steady) { if (!block<0>(q)) return false; }
+      else if (starting && w > 0) { if (!block<4>(q)) return false; }
+      else if (starting) { if (!block<1>(q)) return false; }
+      else if (ending) { if (!block<3>(q)) return false; }
+      else { if (!block<2>(q)) return false; }
     }
-    flush_out(kStripBlock * a.nkq - SUB);      // the last 8 steps' cells (columns <= Y only)
+    flush_out(kStripBlock * a.nkq - SUB);      // the last SUB steps' cells (columns <= Y only)
+    store_masks();
     stamp(5);
     finish();
     return true;

@@ -21,6 +21,23 @@ struct DevPS {
   PW_FN static int32_t shl1(int32_t v, int32_t old) {
     return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   }
+  // wave_shl:1 with zero fill (bound_ctrl): no dependence on an old value, so no copy in front of the DPP move
+  PW_FN static int32_t shl1z(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true); }
+  // value of lane `from` (any lane, through the LDS crossbar: ds_bpermute_b32, counted by lgkmcnt)
+  PW_FN static uint32_t lane_from(uint32_t from, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v);
+  }
+  PW_FN static uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }
+  PW_FN static uint32_t byte_of(uint32_t v, int i) { return __builtin_amdgcn_ubfe(v, 8u * (uint32_t)i, 8u); }   // folds into an SDWA byte select
+  PW_FN static void issue_here() { __builtin_amdgcn_sched_barrier(0); }
+  // 2 h + b as ONE add-with-carry whose carry-in is the comparison's lane mask (the compiler would select and shift-or)
+  PW_FN static int32_t twice_plus(int32_t h, bool b) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(b);
+    int32_t r;
+    uint64_t cout;
+    asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(h), "s"(m));
+    return r;
+  }
   PW_FN static int32_t shfl_xor(int32_t v, int m) { return __shfl_xor(v, m, 64); }
   PW_FN static int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
   PW_FN static bool all(bool p) { return __all(p ? 1 : 0) != 0; }
@@ -71,12 +88,28 @@ struct DevPS {
     typedef const __attribute__((address_space(4))) uint32_t c_u32;
     return ((c_u32*)m)[idx];
   }
+  PW_FN static void letters_x8(const uint8_t* m, int idx, uint32_t (&win)[8]) {
+    typedef const __attribute__((address_space(4))) uint32_t c_u32;
+    typedef uint32_t u8x __attribute__((ext_vector_type(8), aligned(4)));
+    typedef const __attribute__((address_space(4))) u8x c_u8x;
+    const u8x v = *(c_u8x*)((c_u32*)m + idx);
+#pragma unroll
+    for (int d = 0; d < 8; d++) win[d] = v[d];
+  }
   // Loads of the waiting loops: issued and waited for inside one asm statement, so that the compiler's count of
   // outstanding memory operations -- which lets the fast path wait for exactly the load it needs (vmcnt(N)) -- never
   // meets a load inside a loop of unknown length (that would turn every wait into vmcnt(0)).
   PW_FN static uint64_t fifo_poll(const uint64_t* p) {
     uint64_t v;
     asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  }
+  // ... when the writer ran on this XCD: the streaming load (nt) that the hand-over loads use, served by the shared L2,
+  // which has the plain store.  (sc0 alone is workgroup scope and may be served by this CU's L1 for ever; callers mix in
+  // an agent-scope poll every few rounds, so that nothing depends on how a cache treats the hint.)
+  PW_FN static uint64_t fifo_poll_local(const uint64_t* p) {
+    uint64_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
   }
   PW_FN static uint32_t flag_poll(const uint32_t* p) {

@@ -328,7 +328,9 @@ int batch_build(pw_batch* b) {
     if (!d.solvable) continue;
     int bk, nl, nw = 1;
     bool tiled = false;
-    const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
+    // (scores within +-2^25: the strip kernel tracks a row's best as 32 * H + step)
+    const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && (double)maxspan * maxabs < (double)(1 << 25) &&
+                          b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
                           !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED)) && !env_int("PWLIB_NO_STRIP", 0);
     // ... always for tables wider than a workgroup holds; and for the few-pairs case (strip pairs run one after another,
     // each with the whole chip: 2 kb x 2 kb in 0.6 ms against 13.6 ms for one workgroup of 32-diagonal lanes, 8 kb x 8 kb

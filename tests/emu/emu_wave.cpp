@@ -96,8 +96,17 @@ struct EmuPS : EmuP {
     return v != 0;
   }
   static uint32_t readlane(uint32_t v, int i) { Emu* e = Emu::self; return (uint32_t)e->exchange((int)v, i, 0); }
+  static int32_t shl1z(int32_t v) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, 0); }
+  static uint32_t lane_from(uint32_t from, uint32_t v) { Emu* e = Emu::self; return (uint32_t)e->exchange((int)v, (int)from, 0); }
+  static uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t bytes) {
+    return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> (8 * (bytes & 3u)));
+  }
+  static int32_t twice_plus(int32_t h, bool b) { return h + h + (b ? 1 : 0); }
+  static uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xffu; }
+  static void issue_here() {}
   static uint64_t fifo_load(const uint64_t* p) { return *p; }
   static uint64_t fifo_poll(const uint64_t* p) { return *p; }
+  static uint64_t fifo_poll_local(const uint64_t* p) { return *p; }
   static uint64_t fifo_load_local(const uint64_t* p) { return *p; }
   static uint64_t* slot(int s) { static uint64_t slots[2][Emu::N]; return &slots[s][Emu::self->cur]; }
   template <int SLOT> static void fifo_load_async(const uint64_t* p, bool) { *slot(SLOT) = *p; }
@@ -105,6 +114,7 @@ struct EmuPS : EmuP {
   static uint32_t letters_dword(const uint8_t* m, int idx) {
     return (uint32_t)m[4 * idx] | ((uint32_t)m[4 * idx + 1] << 8) | ((uint32_t)m[4 * idx + 2] << 16) | ((uint32_t)m[4 * idx + 3] << 24);
   }
+  static void letters_x8(const uint8_t* m, int idx, uint32_t (&win)[8]) { for (int d = 0; d < 8; d++) win[d] = letters_dword(m, idx + d); }
   static uint32_t flag_poll(const uint32_t* p) { return *p; }
   static void fifo_store(uint64_t* p, uint64_t v) { *p = v; }
   static void fifo_store_local(uint64_t* p, uint64_t v) { *p = v; }

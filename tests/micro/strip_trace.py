@@ -25,9 +25,9 @@ with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1,
     print('fill %.3f ms' % b.fill_ms())
 t = np.fromfile(out, dtype=np.uint64).reshape(-1, 8)
 t0 = t[:, 0].min()
-us = (t[:, :6].astype(np.int64) - int(t0)) / 100.0
+us = (t[:, :7].astype(np.int64) - int(t0)) / 100.0
 xcc = (t[:, 7] & 0xff).astype(int)
-names = ['dequeue', 'setup', 'granules seen', 'step 64', 'step 96', 'end']
+names = ['dequeue', 'setup', 'granules seen', 'step 64', 'step 96', 'end', 'first block past the steady ones']
 print('strips %d; columns: %s (us since the first dequeue)' % (len(t), ', '.join(names)))
 for w in list(range(0, min(len(t), 12))) + list(range(124, min(len(t), 134))) + list(range(len(t) - 3, len(t))):
     if 0 <= w < len(t):
@@ -36,5 +36,10 @@ d = np.diff(us[:, 2])
 print('hop (granules seen, w -> w+1): median %.2f us, mean %.2f, p90 %.2f; same-XCD hops %.2f, cross-XCD %.2f'
       % (np.median(d), d.mean(), np.percentile(d, 90), np.median(d[xcc[1:] == xcc[:-1]]) if (xcc[1:] == xcc[:-1]).any() else -1,
          np.median(d[xcc[1:] != xcc[:-1]]) if (xcc[1:] != xcc[:-1]).any() else -1))
+nst = (Y + 64 + 31) // 32 * 32
+first_end = (Y - 31 + 31) // 32 * 32          # first block with k0 + 31 >= Y
+print('steady part (step 96 -> first end block at step %d): %.1f ns per step; end part (%d steps): median %.2f us = %.1f ns per step'
+      % (first_end, 1000 * np.median(us[:, 6] - us[:, 4]) / max(1, first_end - 96), nst - first_end,
+         np.median(us[:, 5] - us[:, 6]), 1000 * np.median(us[:, 5] - us[:, 6]) / max(1, nst - first_end)))
 print('granules seen -> step 64: median %.2f us; step 64 -> 96: %.2f us; strip total: %.2f us'
       % (np.median(us[:, 3] - us[:, 2]), np.median(us[:, 4] - us[:, 3]), np.median(us[:, 5] - us[:, 2])))
