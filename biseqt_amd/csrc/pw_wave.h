@@ -573,6 +573,9 @@ PW_FN uint32_t max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t,
 // select per half (the very pattern this kernel avoids), and inline asm gets padded with s_nop by the
 // hazard recogniser.  Callers therefore pass the constants in registers made opaque once (pk::opaque).
 PW_FN uint32_t minu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_u2(a), as_u2(b))); }
+PW_FN uint32_t maxu(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(as_u2(a), as_u2(b))); }
+// logical shift right per half by sh = (n, n) held in an opaque register
+PW_FN uint32_t shru(uint32_t a, uint32_t sh) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) >> as_u2(sh))); }
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) * as_u2(b) + as_u2(c))); }
 PW_FN uint32_t mins(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(as_s2(a), as_s2(b))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_alignbit(hi, lo, 16); }
@@ -593,6 +596,11 @@ PW_FN uint32_t minu(uint32_t a, uint32_t b) {
 PW_FN uint32_t mad(uint32_t a, uint32_t b, uint32_t c) {
   return mk((uint32_t)(sl(a) * sl(b) + sl(c)), (uint32_t)(sh(a) * sh(b) + sh(c)));
 }
+PW_FN uint32_t maxu(uint32_t a, uint32_t b) {
+  const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+  return mk(al > bl ? al : bl, ah > bh ? ah : bh);
+}
+PW_FN uint32_t shru(uint32_t a, uint32_t sh) { return mk((a & 0xffffu) >> (sh & 0xfu), (a >> 16) >> ((sh >> 16) & 0xfu)); }
 PW_FN uint32_t mins(uint32_t a, uint32_t b) { return mk((uint32_t)(sl(a) < sl(b) ? sl(a) : sl(b)), (uint32_t)(sh(a) < sh(b) ? sh(a) : sh(b))); }
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 PW_FN uint32_t sign(uint32_t a, uint32_t) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
@@ -649,6 +657,10 @@ struct WaveFill16 {
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
   uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, NEGV, LIMV;
+  // RULE 0, steady blocks: the running best of a slot as a key 8 H + (7 - cell within the block) -- one multiply-add and
+  // one unsigned maximum per cell pair instead of maximum, compare, subtract and multiply-add (H <= 8191: the planner
+  // admits scores up to 8000); turned back into (best, step) once per block
+  uint32_t kbE[RH], kbO[RH], C8, SH3, SEVEN, NEG2;
 
   PW_FN WaveFill16(const FillParams<int32_t>& a_, const WaveDesc& wd_) : a(a_), wd(wd_) {}
 
@@ -695,8 +707,8 @@ struct WaveFill16 {
     if (RULE != 0) Ls = pk::mins(Ls, clampL);
     // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
     acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
-    if (RULE == 0) {
-      const uint32_t Ht = EDGE ? pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV) : Hn;
+    if (RULE == 0 && EDGE) {
+      const uint32_t Ht = pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV);
       const uint32_t bn = pk::max(bests, Ht);
       const uint32_t u = pk::minu(bn ^ bests, ONE);             // 1 where the best strictly improved
       bts = pk::mad(u, tv - bts, bts);                           // steps only grow: no borrow between the halves
@@ -706,6 +718,13 @@ struct WaveFill16 {
       bests = pk::mad(e, pk::sub(bests, Hn), Hn);                // e ? bests : Hn
     }
     Hs = Hn;
+  }
+
+  PW_FN void key_to_best(uint32_t& bests, uint32_t& bts, uint32_t kb, uint32_t kb0, uint32_t base) {
+    const uint32_t ch = pk::minu(kb ^ kb0, ONE);                 // 1 where the best strictly improved in this block
+    const uint32_t st = pk::mad(kb & SEVEN, NEG2, base);         // its step: base - 2 (7 - cell)
+    bts = pk::mad(ch, pk::sub(st, bts), bts);
+    bests = pk::shru(kb, SH3);                                   // (unchanged where the key is)
   }
 
   // HALF selects the accumulator set: iterations 0-3 of a block (cells 0-3 of every slot) or 4-7.
@@ -719,8 +738,11 @@ struct WaveFill16 {
       const uint32_t up0 = pk::align16(UO[RH - 1], prev);         // (prev.hi, own.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
+      {
         cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
                        p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
+        if (RULE == 0 && !EDGE) kbE[p] = pk::maxu(kbE[p], pk::mad(HE[p], C8, pk::both(7 - k)));
+      }
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
     // Only cells outside the table read letters outside a sequence; in steady blocks those are out-of-band
@@ -743,8 +765,11 @@ struct WaveFill16 {
       const uint32_t leftl = pk::align16(nxt, LE[0]);              // (own.hi, next.lo)
 #pragma unroll
       for (int p = 0; p < RH; p++)
+      {
         cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
                        UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
+        if (RULE == 0 && !EDGE) kbO[p] = pk::maxu(kbO[p], pk::mad(HO[p], C8, pk::both(7 - k)));
+      }
     }
     // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
     {
@@ -764,12 +789,28 @@ struct WaveFill16 {
   PW_FN void block16(int b) {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
+    uint32_t kb0E[RH], kb0O[RH];
+    if (RULE == 0 && !EDGE) {
+#pragma unroll
+      for (int p = 0; p < RH; p++) {        // a later cell with the same score loses against 8 best + 7
+        kb0E[p] = kbE[p] = pk::mad(bestE[p], C8, SEVEN); kb0O[p] = kbO[p] = pk::mad(bestO[p], C8, SEVEN);
+      }
+    }
     // unroll depth: full for narrow lanes (the letter-window shifts become register renames), shallower for
     // wide ones, where the live state already fills the register file
 #pragma clang loop unroll_count(UNR)
     for (int k = 0; k < 4; k++) iteration16<EDGE, 0>(8 * b + k, k);
 #pragma clang loop unroll_count(UNR)
     for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
+    if (RULE == 0 && !EDGE) {
+      // cell c of this block (iteration 8 b + c) is step 16 b + 2 c of an even slot, 16 b + 2 c + 1 of an odd one
+      const uint32_t baseE = pk::both(16 * b + 14), baseO = pk::both(16 * b + 15);
+#pragma unroll
+      for (int p = 0; p < RH; p++) {
+        key_to_best(bestE[p], btE[p], kbE[p], kb0E[p], baseE);
+        key_to_best(bestO[p], btO[p], kbO[p], kb0O[p], baseO);
+      }
+    }
     // 8 cells per slot -> one dword, first cell in the top nibble; un-invert: kept = 7 - (not kept).
     // Slots are gathered into their natural order so that every group of 4 goes out as one 16-byte store.
     // Lanes with nothing to store (padding lanes, lanes beyond the plane's rows, blocks past the pair's last)
@@ -849,6 +890,7 @@ struct WaveFill16 {
     yfeed_m = f;
     ONE = pk::opaque(0x00010001u); SH15 = pk::opaque(0x000f000fu);
     C2 = pk::opaque(0x00020002u); C4 = pk::opaque(0x00040004u); C16 = pk::opaque(0x00100010u);
+    C8 = pk::opaque(0x00080008u); SH3 = pk::opaque(0x00030003u); SEVEN = pk::opaque(0x00070007u); NEG2 = pk::opaque(0xfffefffeu);
     NEGV = pk::both(NEG16); LIMV = pk::both(-32767);
     NDELTA = pk::both(a.mismatch - a.match); MATCHV = pk::both(a.match); GOV = pk::both(a.go);
 #pragma unroll
