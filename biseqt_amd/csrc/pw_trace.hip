@@ -89,6 +89,7 @@ PW_DECL(f64, double)
 PW_DECL16(4, 0) PW_DECL16(8, 0) PW_DECL16(12, 0) PW_DECL16(16, 0) PW_DECL16(20, 0) PW_DECL16(24, 0) PW_DECL16(28, 0) PW_DECL16(32, 0)
 PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1)
 PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2)
+PW_DECL16(4, 3) PW_DECL16(8, 3) PW_DECL16(12, 3) PW_DECL16(16, 3) PW_DECL16(20, 3) PW_DECL16(24, 3) PW_DECL16(28, 3) PW_DECL16(32, 3)
 #undef PW_DECL16
 
 hipError_t launch_tile_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
@@ -115,6 +116,7 @@ hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule
     PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
     PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1)
     PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2)
+    PW_CASE16(4, 3) PW_CASE16(8, 3) PW_CASE16(12, 3) PW_CASE16(16, 3) PW_CASE16(20, 3) PW_CASE16(24, 3) PW_CASE16(28, 3) PW_CASE16(32, 3)
     default: return hipErrorInvalidValue;
   }
 #undef PW_CASE16

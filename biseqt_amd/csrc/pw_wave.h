@@ -623,11 +623,17 @@ PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 // beyond its end -- and instead of tracking a best the value of each diagonal's last cell is captured.
 template <class P, int BK, bool SEG, int RULE = 0>
 struct WaveFill16 {
+  // RULE 3 = rule 0 with every score held times 4 (admitted when the scores stay below 2048): a kept-or-not difference
+  // of two running values is then 0 or at least 4, so min(x, 2) and min(x, 4) deliver the D and I tie bits already
+  // weighted and the tie nibble is one three-operand add instead of two multiply-adds.
+  static constexpr bool SC4 = RULE == 3;
+  static constexpr int RL = SC4 ? 0 : RULE;
+  static constexpr int SCL = SC4 ? 4 : 1;
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
   static constexpr int UNR = BK <= 8 ? 4 : (BK <= 16 ? 2 : 1);   // iterations unrolled per loop trip
-  static constexpr int32_t NEG16 = RULE == 0 ? -8192 : -24000;
+  static constexpr int32_t NEG16 = RL == 0 ? -8192 : -24000;
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
   using Base = WaveFill<P, int32_t, BK, true, true, false>;       // only its static feeder helpers are used
 
@@ -656,7 +662,7 @@ struct WaveFill16 {
   uint32_t tfE[RH], tfO[RH], tlE[RH], tlO[RH];          // first / last step of each diagonal
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
-  uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, NEGV, LIMV;
+  uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, GOVI, NEGV, LIMV;
   // RULE 0, steady blocks: the running best of a slot as a key 8 H + (7 - cell within the block) -- one multiply-add and
   // one unsigned maximum per cell pair instead of maximum, compare, subtract and multiply-add (H <= 8191: the planner
   // admits scores up to 8000); turned back into (best, step) once per block
@@ -688,7 +694,7 @@ struct WaveFill16 {
     const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
     uint32_t Hn = pk::max(pk::max(up, left), hM);
     uint32_t nB;
-    if (RULE == 0) {
+    if (RL == 0) {
       if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
       else Hn = pk::max(Hn, 0u);                                 // B: an alignment may begin anywhere, score 0
       nB = pk::minu(Hn, ONE);
@@ -699,15 +705,16 @@ struct WaveFill16 {
       nB = pk::minu(Hn ^ Bc, ONE);
     }
     // "is the candidate kept" only asks whether H == candidate: xor (a 2-cycle op) instead of a packed subtract
-    const uint32_t nD = pk::minu(Hn ^ up, ONE);
-    const uint32_t nI = pk::minu(Hn ^ left, ONE);
+    const uint32_t nD = pk::minu(Hn ^ up, SC4 ? C2 : ONE);       // SC4: 0 or 2
+    const uint32_t nI = pk::minu(Hn ^ left, SC4 ? C4 : ONE);     // SC4: 0 or 4
     const uint32_t hg = pk::add(Hn, geb);
     Us = pk::mad(nD, GOV, hg);                                   // (H + ge) + go unless a D choice is kept
-    Ls = pk::mad(nI, GOV, hg);
-    if (RULE != 0) Ls = pk::mins(Ls, clampL);
+    Ls = pk::mad(nI, GOVI, hg);
+    if (RL != 0) Ls = pk::mins(Ls, clampL);
     // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
-    acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
-    if (RULE == 0 && EDGE) {
+    if (SC4) acc = pk::mad(acc, C16, nB + nD + nI);             // (halves below 8: a plain 32-bit three-operand add)
+    else acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
+    if (RL == 0 && EDGE) {
       const uint32_t Ht = pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV);
       const uint32_t bn = pk::max(bests, Ht);
       const uint32_t u = pk::minu(bn ^ bests, ONE);             // 1 where the best strictly improved
@@ -724,7 +731,8 @@ struct WaveFill16 {
     const uint32_t ch = pk::minu(kb ^ kb0, ONE);                 // 1 where the best strictly improved in this block
     const uint32_t st = pk::mad(kb & SEVEN, NEG2, base);         // its step: base - 2 (7 - cell)
     bts = pk::mad(ch, pk::sub(st, bts), bts);
-    bests = pk::shru(kb, SH3);                                   // (unchanged where the key is)
+    // (unchanged where the key is; SC4: key = 2 (4 H) + cell)
+    bests = SC4 ? (pk::shru(kb, ONE) & 0xfffcfffcu) : pk::shru(kb, SH3);
   }
 
   // HALF selects the accumulator set: iterations 0-3 of a block (cells 0-3 of every slot) or 4-7.
@@ -741,7 +749,7 @@ struct WaveFill16 {
       {
         cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
                        p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
-        if (RULE == 0 && !EDGE) kbE[p] = pk::maxu(kbE[p], pk::mad(HE[p], C8, pk::both(7 - k)));
+        if (RL == 0 && !EDGE) kbE[p] = pk::maxu(kbE[p], pk::mad(HE[p], SC4 ? C2 : C8, pk::both(7 - k)));
       }
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
@@ -768,7 +776,7 @@ struct WaveFill16 {
       {
         cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
                        UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
-        if (RULE == 0 && !EDGE) kbO[p] = pk::maxu(kbO[p], pk::mad(HO[p], C8, pk::both(7 - k)));
+        if (RL == 0 && !EDGE) kbO[p] = pk::maxu(kbO[p], pk::mad(HO[p], SC4 ? C2 : C8, pk::both(7 - k)));
       }
     }
     // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
@@ -790,10 +798,10 @@ struct WaveFill16 {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
     uint32_t kb0E[RH], kb0O[RH];
-    if (RULE == 0 && !EDGE) {
+    if (RL == 0 && !EDGE) {
 #pragma unroll
       for (int p = 0; p < RH; p++) {        // a later cell with the same score loses against 8 best + 7
-        kb0E[p] = kbE[p] = pk::mad(bestE[p], C8, SEVEN); kb0O[p] = kbO[p] = pk::mad(bestO[p], C8, SEVEN);
+        kb0E[p] = kbE[p] = pk::mad(bestE[p], SC4 ? C2 : C8, SEVEN); kb0O[p] = kbO[p] = pk::mad(bestO[p], SC4 ? C2 : C8, SEVEN);
       }
     }
     // unroll depth: full for narrow lanes (the letter-window shifts become register renames), shallower for
@@ -802,7 +810,7 @@ struct WaveFill16 {
     for (int k = 0; k < 4; k++) iteration16<EDGE, 0>(8 * b + k, k);
 #pragma clang loop unroll_count(UNR)
     for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
-    if (RULE == 0 && !EDGE) {
+    if (RL == 0 && !EDGE) {
       // cell c of this block (iteration 8 b + c) is step 16 b + 2 c of an even slot, 16 b + 2 c + 1 of an odd one
       const uint32_t baseE = pk::both(16 * b + 14), baseO = pk::both(16 * b + 15);
 #pragma unroll
@@ -862,7 +870,7 @@ struct WaveFill16 {
   PW_FN int tbegin_of(int j) const {      // RULE != 0: the step of the diagonal's cell that may begin an alignment
     const int dd = li * BK + j, d = pd.dmin + dd;
     if (!valid || dd >= ndiag) return 32767;
-    if (RULE == 2 && d != 0) return 32767;                 // B_GLOBAL: cell (0, 0) only
+    if (RL == 2 && d != 0) return 32767;                 // B_GLOBAL: cell (0, 0) only
     return (d < 0 ? -d : d) - pd.s0;                       // the first cell of the diagonal lies on the table edge
   }
   PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)X ? (uint32_t)oseq[i] : SENT_O; }
@@ -892,13 +900,15 @@ struct WaveFill16 {
     C2 = pk::opaque(0x00020002u); C4 = pk::opaque(0x00040004u); C16 = pk::opaque(0x00100010u);
     C8 = pk::opaque(0x00080008u); SH3 = pk::opaque(0x00030003u); SEVEN = pk::opaque(0x00070007u); NEG2 = pk::opaque(0xfffefffeu);
     NEGV = pk::both(NEG16); LIMV = pk::both(-32767);
-    NDELTA = pk::both(a.mismatch - a.match); MATCHV = pk::both(a.match); GOV = pk::both(a.go);
+    NDELTA = pk::both(SCL * (a.mismatch - a.match)); MATCHV = pk::both(SCL * a.match);
+    // the multipliers of the "not kept" values: 0 / 1 each, or (SC4) 0 / 2 for D and 0 / 4 for I
+    GOV = pk::both(SC4 ? 2 * a.go : a.go); GOVI = pk::both(a.go);
 #pragma unroll
     for (int p = 0; p < RH; p++) {
       const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      if (RULE == 0) {
-        gebE[p] = pk::pack(a.ge + blocked(e0), a.ge + blocked(e1));
-        gebO[p] = pk::pack(a.ge + blocked(o0), a.ge + blocked(o1));
+      if (RL == 0) {
+        gebE[p] = pk::pack(SCL * a.ge + blocked(e0), SCL * a.ge + blocked(e1));
+        gebO[p] = pk::pack(SCL * a.ge + blocked(o0), SCL * a.ge + blocked(o1));
         tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
         clE[p] = clO[p] = 0;
       } else {
@@ -915,7 +925,7 @@ struct WaveFill16 {
     }
     // The planner's steady range allows a diagonal's LAST cell to be the last step of a steady block (every cell of
     // the block is still valid); rules 1 / 2 capture that cell, which only the edge body does: give up that block.
-    const int sb1 = RULE == 0 ? wd.steady_b1 : wd.steady_b1 - 1;
+    const int sb1 = RL == 0 ? wd.steady_b1 : wd.steady_b1 - 1;
     feed_issue(0);
     for (int b = 0; b < wd.nblocks; b++) {
       feed_commit(b);
@@ -946,19 +956,19 @@ struct WaveFill16 {
       for (int h = 0; h < 2; h++) {
         const int j = 2 * p + odd + h * R;
         const int dd = li * BK + j, d = pd.dmin + dd;
-        const int32_t s = h ? pk::hi_s(bq) : pk::lo_s(bq);
+        const int32_t s = (h ? pk::hi_s(bq) : pk::lo_s(bq)) / SCL;   // (exact: every running value is a multiple of SCL)
         const int bt = (int)(h ? (tq >> 16) : (tq & 0xffffu));
         const int tfirst = (d < 0 ? -d : d) - pd.s0;
         const int aa = (bt - tfirst) >> 1;
         int x = aa + (d > 0 ? d : 0), y = aa - (d < 0 ? d : 0);
         uint64_t k;
         bool ok = true;
-        if (RULE != 0) {
+        if (RL != 0) {
           // `s` is the captured value of the diagonal's last cell (_banded_find_optimal, _pw_internals.c:364-414)
           const bool ends_right = d < X - Y;
           x = ends_right ? d + Y : X; y = ends_right ? Y : X - d;
           k = (uint64_t)(uint32_t)dd;
-          if (RULE == 2) ok = d == X - Y;
+          if (RL == 2) ok = d == X - Y;
         } else if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
         else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
         const bool better = ok && valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));

@@ -391,6 +391,9 @@ int batch_build(pw_batch* b) {
     // consecutive (similar length) pairs share a wavefront
     const int ppw = pseg ? 64 / pnl : 1;
     b->packed_seg = pseg; b->packed_rule = prule;
+    // rule 0, one pair per wavefront, scores below 2048: the kernel that holds every score times 4 (WaveFill16, RULE 3)
+    if (prule == 0 && !pseg && (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 2047 && !env_int("PWLIB_NO_SCALED16", 0))
+      b->packed_rule = 3;
     BkClass& c = b->classes[0];
     for (size_t i = 0; i < c.order.size(); i += ppw) {
       pw::WaveDesc wd;
@@ -656,7 +659,8 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   if (nw > 1) { snprintf(name, sizeof name, "k_fill_mw<%s, %d, ...> x %d wavefronts", t, bk, nw); return name; }
   switch (b->variant) {
     case pw::VAR_FAST16:
-      if (b->packed_rule) snprintf(name, sizeof name, "k_fill16<%d, %s, %d>", bk, b->packed_seg ? "true" : "false", b->packed_rule);
+      if (b->packed_rule == 3) snprintf(name, sizeof name, "k_fill16<%d, %s> x4", bk, b->packed_seg ? "true" : "false");
+      else if (b->packed_rule) snprintf(name, sizeof name, "k_fill16<%d, %s, %d>", bk, b->packed_seg ? "true" : "false", b->packed_rule);
       else snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false");
       break;
     case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;

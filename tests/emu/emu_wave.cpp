@@ -165,7 +165,9 @@ template <int BK> struct Run16<int32_t, BK> {
       Emu emu;
       const int rule = a.endrule == pw::END_BANDED_OVERLAP ? 1 : (a.endrule == pw::END_CORNER ? 2 : 0);
       if (rule == 0) {
-        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 0> w(a, wd); w.run(); });
+        // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048)
+        if (g_packed_mode == 3) emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 3> w(a, wd); w.run(); });
+        else if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 0> w(a, wd); w.run(); });
         else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 0> w(a, wd); w.run(); });
       } else if (rule == 1) {
         if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 1> w(a, wd); w.run(); });

@@ -281,7 +281,7 @@ def test_config2_properties_full_size(oracle):
     with BatchAligner(list(zip(origins, mutants)), alnmode=1, alntype=1, alphabet_len=4,
                       diag_range=(-200, 200), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as b:
         assert b.score_dtype == 'i32'
-        assert b.kernel_name == 'k_fill16<8, false>'      # the kernel bench.py's headline line reports
+        assert b.kernel_name == 'k_fill16<8, false> x4'   # the kernel bench.py's headline line reports (scores held times 4)
         cells = b.cells
         res = b.run()
         txs = b.transcripts(res)
@@ -324,12 +324,18 @@ def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
     kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-200, 200), match_score=1, mismatch_score=-3,
               go_score=-5, ge_score=-2)
     runs = {}
-    for name, flags in (('packed16', 0), ('int32', W.PW_FLAG_NO_PACKED16), ('f64', W.PW_FLAG_FORCE_F64)):
-        with BatchAligner(pairs, flags=flags, **kw) as b:
-            kname = b.kernel_name
-            res = b.run()
-            runs[name] = (kname, res.copy(), b.transcripts(res))
-    assert runs['packed16'][0] == 'k_fill16<8, false>'
+    for name, flags in (('packed16', 0), ('packed16_unscaled', 0), ('int32', W.PW_FLAG_NO_PACKED16), ('f64', W.PW_FLAG_FORCE_F64)):
+        if name == 'packed16_unscaled':
+            os.environ['PWLIB_NO_SCALED16'] = '1'
+        try:
+            with BatchAligner(pairs, flags=flags, **kw) as b:
+                kname = b.kernel_name
+                res = b.run()
+                runs[name] = (kname, res.copy(), b.transcripts(res))
+        finally:
+            os.environ.pop('PWLIB_NO_SCALED16', None)
+    assert runs['packed16'][0] == 'k_fill16<8, false> x4'
+    assert runs['packed16_unscaled'][0] == 'k_fill16<8, false>'
     assert runs['int32'][0] == 'k_fill<int, 8, true, true, false>'
     assert runs['f64'][0] == 'k_fill<double, 8, true, true, false>'
     kname, res, txs = runs['packed16']
@@ -346,7 +352,7 @@ def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
                          match=1, mismatch=-3, go=-5, ge=-2)
         assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score'], k
         assert txs[k] == r['transcript'], k
-    for other in ('int32', 'f64'):
+    for other in ('packed16_unscaled', 'int32', 'f64'):
         _, res2, txs2 = runs[other]
         assert (res2 == res).all(), other
         assert txs2 == txs, other
@@ -380,6 +386,48 @@ def test_packed16_admission_with_mismatch_above_match(oracle):
         assert txs[0] == r['transcript']
         if not packed:
             assert r['score'] > 32767
+
+
+def test_scaled_packed_kernel_at_its_admission_bound(oracle):
+    """The packed kernel that holds every score times 4 (WaveFill16 RULE 3) is taken while min(X, Y) * max(match, mismatch)
+    stays below 2048: identical sequences whose score reaches 2045 and 2047 must take it and equal the unscaled packed kernel,
+    the 32-bit kernel and the oracle; one letter more (2050) must fall back to the unscaled kernel."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(77)
+    for n, match, mismatch, scaled in ((409, 5, -4, True), (2047, 1, -3, True), (2047, 1, 0, True), (410, 5, -4, False),
+                                       (341, 2, 6, True), (342, 2, 6, False)):
+        o = synth.rand_seqs(rng, 1, n)[0]
+        m2 = synth.mutate(rng, o, 0.05, 0.02, 0.3)
+        kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-200, 200), match_score=match, mismatch_score=mismatch,
+                  go_score=-5, ge_score=-2)
+        pairs = [(o, o.copy())] * 150 + [(o, m2)] * 150 + [(m2, o)] * 20    # enough pairs to leave latency mode
+        if min(len(o), len(m2)) < n and scaled is False:
+            pairs = [(o, o.copy())] * 320
+        runs = []
+        for env, flags in (('', 0), ('1', 0), ('', W.PW_FLAG_NO_PACKED16)):
+            if env:
+                os.environ['PWLIB_NO_SCALED16'] = env
+            try:
+                with BatchAligner(pairs, flags=flags, **kw) as b:
+                    name = b.kernel_name
+                    res = b.run()
+                    runs.append((name, res.copy(), b.transcripts(res)))
+            finally:
+                os.environ.pop('PWLIB_NO_SCALED16', None)
+        assert ('x4' in runs[0][0]) == scaled, (n, match, runs[0][0])
+        assert 'k_fill16' in runs[1][0] and 'x4' not in runs[1][0]
+        assert 'k_fill16' not in runs[2][0]
+        for other in runs[1:]:
+            assert (other[1] == runs[0][1]).all() and other[2] == runs[0][2], (n, match, other[0])
+        for k in (0, len(pairs) - 1):
+            r = oracle.solve(pairs[k][0], pairs[k][1], L=4, mode=1, alntype=1, diag_range=(-200, 200), match=match,
+                             mismatch=mismatch, go=-5, ge=-2)
+            assert (runs[0][1]['opt_i'][k], runs[0][1]['opt_j'][k]) == r['opt'] and runs[0][1]['score'][k] == r['score']
+            assert runs[0][2][k] == r['transcript']
+        if scaled and mismatch < match:
+            assert runs[0][1]['score'][0] == n * match
 
 
 def test_traceback_from_explicit_end_cells(oracle):
