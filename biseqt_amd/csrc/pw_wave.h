@@ -686,16 +686,19 @@ struct WaveFill16 {
   // For RULE != 0: `bests` holds the captured value of the diagonal's LAST cell, `bts` is unused, `tf` is the step of
   // the one cell that may begin an alignment (32767 = none), `geb` is ge in both halves and `clampL` silences the
   // first diagonal above the band.
-  template <bool EDGE>
+  // EK: 0 steady; bit 0: some diagonal of the wavefront has not started yet in this block; bit 1: some has ended (rules
+  // 1 / 2 know steady and "edge" = 3 only).
+  template <int EK>
   PW_FN void cellpair(uint32_t& Hs, uint32_t& Us, uint32_t& Ls, uint32_t& bests, uint32_t& bts, uint32_t geb,
                       uint32_t tf, uint32_t tl, uint32_t& acc, uint32_t up, uint32_t left, uint32_t oc,
                       uint32_t mc, uint32_t tv, uint32_t clampL = 0) {
+    constexpr bool EDGE = EK != 0;
     const uint32_t ne = pk::minu(oc ^ mc, ONE);                 // 0 where the letters match
     const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
     uint32_t Hn = pk::max(pk::max(up, left), hM);
     uint32_t nB;
     if (RL == 0) {
-      if (EDGE) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
+      if (EK & 1) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
       else Hn = pk::max(Hn, 0u);                                 // B: an alignment may begin anywhere, score 0
       nB = pk::minu(Hn, ONE);
     } else {
@@ -714,12 +717,8 @@ struct WaveFill16 {
     // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
     if (SC4) acc = pk::mad(acc, C16, nB + nD + nI);             // (halves below 8: a plain 32-bit three-operand add)
     else acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
-    if (RL == 0 && EDGE) {
-      const uint32_t Ht = pk::add(Hn, pk::sign(pk::sub(tl, tv), SH15) & LIMV);
-      const uint32_t bn = pk::max(bests, Ht);
-      const uint32_t u = pk::minu(bn ^ bests, ONE);             // 1 where the best strictly improved
-      bts = pk::mad(u, tv - bts, bts);                           // steps only grow: no borrow between the halves
-      bests = bn;
+    if (RL == 0) {
+      // (the running best is kept as a key by iteration16)
     } else if (EDGE) {
       const uint32_t e = pk::minu(tv ^ tl, ONE);                 // 0 in the diagonal's last cell
       bests = pk::mad(e, pk::sub(bests, Hn), Hn);                // e ? bests : Hn
@@ -736,8 +735,19 @@ struct WaveFill16 {
   }
 
   // HALF selects the accumulator set: iterations 0-3 of a block (cells 0-3 of every slot) or 4-7.
-  template <bool EDGE, int HALF>
+  // Rule 0: the slot's running best as a key (see kbE): cells of a diagonal that has not started hold the sentinel and
+  // count as 0, cells beyond a diagonal's end are masked out -- neither can beat 8 best + 7.
+  template <int EK>
+  PW_FN void track_key(uint32_t& kb, uint32_t H, uint32_t tl, uint32_t tv, int k) {
+    const uint32_t hk = (EK & 1) ? pk::max(H, 0u) : H;
+    uint32_t key = pk::mad(hk, SC4 ? C2 : C8, pk::both(7 - k));
+    if (EK & 2) key &= ~pk::sign(pk::sub(tl, tv), SH15);
+    kb = pk::maxu(kb, key);
+  }
+
+  template <int EK, int HALF>
   PW_FN void iteration16(int it, int k) {
+    constexpr bool EDGE = EK != 0;
     const uint32_t tv0 = pk::both(2 * it), tv1 = pk::both(2 * it + 1);
     // even step: slot 0 <- previous lane's last slot, slot R <- own slot R - 1
     {
@@ -747,9 +757,9 @@ struct WaveFill16 {
 #pragma unroll
       for (int p = 0; p < RH; p++)
       {
-        cellpair<EDGE>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
-                       p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
-        if (RL == 0 && !EDGE) kbE[p] = pk::maxu(kbE[p], pk::mad(HE[p], SC4 ? C2 : C8, pk::both(7 - k)));
+        cellpair<EK>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
+                     p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
+        if (RL == 0) track_key<EK>(kbE[p], HE[p], tlE[p], tv0, k);
       }
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
@@ -774,9 +784,9 @@ struct WaveFill16 {
 #pragma unroll
       for (int p = 0; p < RH; p++)
       {
-        cellpair<EDGE>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
-                       UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
-        if (RL == 0 && !EDGE) kbO[p] = pk::maxu(kbO[p], pk::mad(HO[p], SC4 ? C2 : C8, pk::both(7 - k)));
+        cellpair<EK>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
+                     UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
+        if (RL == 0) track_key<EK>(kbO[p], HO[p], tlO[p], tv1, k);
       }
     }
     // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
@@ -793,12 +803,12 @@ struct WaveFill16 {
     }
   }
 
-  template <bool EDGE>
+  template <int EK>
   PW_FN void block16(int b) {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
     uint32_t kb0E[RH], kb0O[RH];
-    if (RL == 0 && !EDGE) {
+    if (RL == 0) {
 #pragma unroll
       for (int p = 0; p < RH; p++) {        // a later cell with the same score loses against 8 best + 7
         kb0E[p] = kbE[p] = pk::mad(bestE[p], SC4 ? C2 : C8, SEVEN); kb0O[p] = kbO[p] = pk::mad(bestO[p], SC4 ? C2 : C8, SEVEN);
@@ -807,10 +817,10 @@ struct WaveFill16 {
     // unroll depth: full for narrow lanes (the letter-window shifts become register renames), shallower for
     // wide ones, where the live state already fills the register file
 #pragma clang loop unroll_count(UNR)
-    for (int k = 0; k < 4; k++) iteration16<EDGE, 0>(8 * b + k, k);
+    for (int k = 0; k < 4; k++) iteration16<EK, 0>(8 * b + k, k);
 #pragma clang loop unroll_count(UNR)
-    for (int k = 4; k < 8; k++) iteration16<EDGE, 1>(8 * b + k, k);
-    if (RL == 0 && !EDGE) {
+    for (int k = 4; k < 8; k++) iteration16<EK, 1>(8 * b + k, k);
+    if (RL == 0) {
       // cell c of this block (iteration 8 b + c) is step 16 b + 2 c of an even slot, 16 b + 2 c + 1 of an odd one
       const uint32_t baseE = pk::both(16 * b + 14), baseO = pk::both(16 * b + 15);
 #pragma unroll
@@ -919,7 +929,9 @@ struct WaveFill16 {
       }
       tlE[p] = pk::pack(tlast_of(e0), tlast_of(e1)); tlO[p] = pk::pack(tlast_of(o0), tlast_of(o1));
       HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
-      bestE[p] = bestO[p] = NEGV; btE[p] = btO[p] = 0;
+      // rule 0: scores never go below 0, and a diagonal whose best stays 0 reports its first cell (score 0 on the table edge)
+      bestE[p] = bestO[p] = RL == 0 ? 0u : NEGV;
+      btE[p] = RL == 0 ? tfE[p] : 0u; btO[p] = RL == 0 ? tfO[p] : 0u;
       OW[p] = pk::pack((int32_t)letter_o(xbase + p - 1), (int32_t)letter_o(xbase + p + RH - 1));
       MW[p] = pk::pack((int32_t)letter_m(ybase - p - 1), (int32_t)letter_m(ybase - p - RH - 1));
     }
@@ -930,8 +942,11 @@ struct WaveFill16 {
     for (int b = 0; b < wd.nblocks; b++) {
       feed_commit(b);
       if (b + 1 < wd.nblocks) feed_issue(b + 1);
-      if (b >= wd.steady_b0 && b < sb1) block16<false>(b);
-      else block16<true>(b);
+      if (b >= wd.steady_b0 && b < sb1) block16<0>(b);
+      else if (RL != 0) block16<3>(b);
+      else if (b >= wd.steady_b0) block16<2>(b);                   // every diagonal has started, some may have ended
+      else if (sb1 > wd.steady_b0) block16<1>(b);                  // some have not started; none has ended before the steady range
+      else block16<3>(b);                                          // (no steady range: the planner's bounds cannot tell)
     }
     finish();
   }
