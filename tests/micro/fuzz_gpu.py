@@ -74,6 +74,7 @@ def make_band(rng, X, Y, o, m):
 def run(budget, seed, long_mode=False, max_batches=None):
     rng = np.random.default_rng(seed)
     t0 = time.time()
+    nb = npairs = kernels = {}
     nb = npairs = nbad = 0
     last = t0
     while time.time() - t0 < budget and (max_batches is None or nb < max_batches):
@@ -98,9 +99,16 @@ def run(budget, seed, long_mode=False, max_batches=None):
                   go_score=sc[2], ge_score=sc[3], flags=flags, check_band=False)
         if mode == 1:
             kw['diag_range'] = bands
+        # kernel selection knobs the planner reads at batch creation: throughput kernels for small batches, the unscaled
+        # packed kernel where the scaled one would be taken
+        for name, p_on in (('PWLIB_LATENCY_MODE', 0.3), ('PWLIB_NO_SCALED16', 0.3)):
+            os.environ.pop(name, None)
+            if rng.random() < p_on:
+                os.environ[name] = '0' if name == 'PWLIB_LATENCY_MODE' else '1'
         try:
             with BatchAligner(pairs, **kw) as b:
                 kname = b.kernel_name
+                kernels[kname.split('(')[0]] = kernels.get(kname.split('(')[0], 0) + 1
                 res = b.run()
                 txs = b.transcripts(res)
                 rcs = [b.init_rc(k) for k in range(n)]
@@ -138,6 +146,7 @@ def run(budget, seed, long_mode=False, max_batches=None):
         if time.time() - last > 30:
             last = time.time()
             print('... %d batches, %d pairs, %d bad' % (nb, npairs, nbad), flush=True)
+    print('kernels: ' + ', '.join('%s x%d' % kv for kv in sorted(kernels.items(), key=lambda kv: -kv[1])))
     print('fuzz: %d batches, %d pairs, %d mismatches (seed %d, %.0f s)' % (nb, npairs, nbad, seed, time.time() - t0))
     return nb, npairs, nbad
 
