@@ -100,6 +100,7 @@ struct StripFill {
   // next cell, the row's letter and the mutant letter that travels with the wavefront
   int32_t Hout, Uout, Lo, Hdiag, best, bestY, hlast, b0, bfirst;
   int32_t kbest;              // steady blocks: the row's running best as a key, 32 * H + (31 - step within the block)
+  int32_t ksnap, kY;          // MODE 3: the key as it was on the step of the row's last cell; that step (Y + lane)
   int32_t bqv;                // MODE 4: the begin candidate of this lane's current cell (moves down one lane per step)
   uint32_t oc;
   // the mutant letters this lane meets: lane i needs m[k - 1 - i] at step k, so over the 4 steps of a group (k = 4 g ..
@@ -188,11 +189,14 @@ struct StripFill {
     } else if (MODE == 3) {
       macc = (macc << 4) | nib;
       Hout = Hn; Uout = Un; Lo = Ln;
-      const bool real = y <= a.Y;
-      hlast = y == a.Y ? Hn : hlast;
+      // the row's last cell is computed on step kY = Y + lane; cells after it are virtual.  The running key takes them too,
+      // so its value at that step is set aside (block<3> then picks, per lane, the snapshot, the key or nothing)
+      const bool last = k == kY;
+      hlast = last ? Hn : hlast;
       if (TRACK) {
-        const bool upd = real && Hn > best;
-        best = upd ? Hn : best; bestY = upd ? y : bestY;
+        const int32_t key = (int32_t)(((uint32_t)Hn << 5) | (uint32_t)(31 - j));
+        kbest = key > kbest ? key : kbest;
+        ksnap = last ? kbest : ksnap;
       }
     } else {
       // (MODE 1: the masks of virtual cells are never visited by the walker, and their scores lose against any real
@@ -362,10 +366,10 @@ struct StripFill {
     for (int d = 0; d < 8; d++) mwin[d] = mnext[d];
     uint32_t mw[4];
     int32_t kb0 = 0;
-    if (TRACK && (MODE == 0 || MODE == 4)) {
+    if (TRACK && (MODE == 0 || MODE == 3 || MODE == 4)) {
       const int32_t floor25 = -(1 << 25);
       kb0 = (int32_t)(((uint32_t)(best > floor25 ? best : floor25) << 5) | 31u);   // an equal score later in the row loses
-      kbest = kb0;
+      kbest = kb0; ksnap = kb0;
     }
     if (!sub_block<MODE, 0>(q, mw)) return false;
     if (!sub_block<MODE, 1>(q, mw)) return false;
@@ -376,10 +380,16 @@ struct StripFill {
 #pragma unroll
     for (int d = 0; d < 4; d++) mprev[d] = mw[d];
     mprev_q = q;
-    if (TRACK && (MODE == 0 || MODE == 4)) {
-      const bool ch = kbest != kb0;
-      best = ch ? (kbest >> 5) : best;
-      bestY = ch ? kStripBlock * q + (31 - (kbest & 31)) - lane : bestY;
+    if (TRACK && (MODE == 0 || MODE == 3 || MODE == 4)) {
+      int32_t kb = kbest;
+      if (MODE == 3) {
+        // rows whose last cell lies in this block take the snapshot, rows that ended before it nothing
+        const int k0 = kStripBlock * q;
+        kb = kY < k0 ? kb0 : (kY < k0 + kStripBlock ? ksnap : kbest);
+      }
+      const bool ch = kb != kb0;
+      best = ch ? (kb >> 5) : best;
+      bestY = ch ? kStripBlock * q + (31 - (kb & 31)) - lane : bestY;
     }
     return true;
   }
@@ -394,7 +404,7 @@ struct StripFill {
     const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
     oc = (uint32_t)P::in_vgpr((int32_t)oseq[oi]);      // opaque: a compare known to be 8 bits wide is not folded into a byte select
     w0 = 0; w1 = 0; wpend = 0; wshift = 3u - ((uint32_t)lane & 3u); wfrom = (uint32_t)((lane - 4) & 63);
-    kbest = 0; mprev_q = -1; bqv = NEG;
+    kbest = 0; mprev_q = -1; bqv = NEG; ksnap = 0; kY = a.Y + lane;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
     gP = 0; cH = NEG; cU = NEG;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
