@@ -106,6 +106,7 @@ PW_FLAG_DUMP_SCORES, PW_FLAG_FORCE_F64, PW_FLAG_FORCE_GENERIC, PW_FLAG_PROFILE =
 PW_FLAG_NO_PACKED16 = 16
 PW_FLAG_FORCE_TILED = 32
 PW_FLAG_FORCE_STRIP = 64
+PW_FLAG_SHARED_ARENA = 128
 
 SIZEOF = dict(intpair=8, alnscores=24, alnframe=32, std_alnparams=4, banded_alnparams=12,
               alnprob=32, alnchoice=32, dpcell=16, dptable=32, alignment=24,
@@ -116,7 +117,7 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_last_error', 'pw_device_count', 'pw_device_memory', 'pw_pool_trim', 'pw_batch_create', 'pw_batch_destroy',
            'pw_batch_init_rc', 'pw_batch_band', 'pw_batch_pair_cells', 'pw_batch_cells',
            'pw_batch_algorithmic_bytes', 'pw_batch_score_type', 'pw_batch_kernel_name', 'pw_batch_upload_arena',
-           'pw_batch_arena_device', 'pw_host_alloc', 'pw_host_free', 'pw_batch_upload_arena_async',
+           'pw_batch_arena_device', 'pw_arena_upload', 'pw_arena_free', 'pw_batch_share_arena', 'pw_host_alloc', 'pw_host_free', 'pw_batch_upload_arena_async',
            'pw_batch_results_async', 'pw_batch_transcripts_async', 'pw_batch_solve', 'pw_batch_traceback',
            'pw_batch_traceback_from', 'pw_batch_sync', 'pw_batch_results_device',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
@@ -223,6 +224,11 @@ def load():
     lib.pw_batch_upload_arena.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     lib.pw_batch_arena_device.argtypes = [C.c_void_p]
     lib.pw_batch_arena_device.restype = C.c_void_p
+    lib.pw_arena_upload.argtypes = [C.c_int, C.c_void_p, C.c_uint64]
+    lib.pw_arena_upload.restype = C.c_void_p
+    lib.pw_arena_free.argtypes = [C.c_int, C.c_void_p]
+    lib.pw_arena_free.restype = None
+    lib.pw_batch_share_arena.argtypes = [C.c_void_p, C.c_void_p]
     lib.pw_host_alloc.argtypes = [C.c_uint64]
     lib.pw_host_alloc.restype = C.c_void_p
     lib.pw_host_free.argtypes = [C.c_void_p]

@@ -87,6 +87,35 @@ def pack_reads(reads):
     return arena, offs, lens.astype(np.int32)
 
 
+class DeviceArena(object):
+    """One device copy of a read arena (:func:`pack_reads`) for all the batches of a job (``pw_arena_upload``)."""
+
+    def __init__(self, arena, device=0):
+        self.lib = W.load()
+        arena = np.ascontiguousarray(arena, np.uint8)
+        self.device, self.nbytes = device, arena.nbytes
+        self.ptr = self.lib.pw_arena_upload(device, arena.ctypes.data, arena.nbytes)
+        if not self.ptr:
+            raise RuntimeError('pw_arena_upload failed: ' + W.last_error())
+
+    def close(self):
+        if self.ptr:
+            self.lib.pw_arena_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BatchAligner(object):
     """Plan, upload, solve and trace back a batch of pairs.
 
@@ -162,10 +191,12 @@ class BatchAligner(object):
             self.upload()
 
     @classmethod
-    def from_arena(cls, arena, offsets, lengths, pairs, diag_ranges=None, **kw):
+    def from_arena(cls, arena, offsets, lengths, pairs, diag_ranges=None, device_arena=None, **kw):
         """Pairs that REFER to reads of one shared arena (:func:`pack_reads`) instead of carrying copies: ``pairs`` is
         an (n, 2) array of read indices (origin, mutant), ``diag_ranges`` an (n, 2) array in banded mode.  This is the
-        shape of overlap pipelines, where every read takes part in dozens of pairs."""
+        shape of overlap pipelines, where every read takes part in dozens of pairs.  With ``device_arena`` (a
+        :class:`DeviceArena` of the same arena) the batch reads the reads from that device copy -- uploaded once for
+        all the batches of a job -- instead of allocating and uploading its own."""
         self = cls.__new__(cls)
         self.lib = W.load()
         self.alnmode = kw.get('alnmode', W.STD_MODE)
@@ -200,12 +231,17 @@ class BatchAligner(object):
         sc = W.pw_scoring(self.alnmode, self.alntype, L, S.ctypes.data_as(C.POINTER(C.c_double)),
                           float(self.go_score), float(self.ge_score))
         self.device = kw.get('device', 0)
-        self.flags = kw.get('flags', 0)
+        self.flags = kw.get('flags', 0) | (W.PW_FLAG_SHARED_ARENA if device_arena is not None else 0)
         self.handle = self.lib.pw_batch_create(self.device, C.byref(sc), self.n, rec.ctypes.data_as(C.POINTER(W.pw_pair)),
                                                self.arena.nbytes, self.flags)
         if not self.handle:
             raise RuntimeError('pw_batch_create failed: ' + W.last_error())
-        self.upload()
+        if device_arena is not None:
+            assert device_arena.device == self.device and device_arena.nbytes >= self.arena.nbytes
+            self._device_arena = device_arena          # keeps it alive as long as the batch
+            self._ck(self.lib.pw_batch_share_arena(self.handle, device_arena.ptr), 'pw_batch_share_arena')
+        else:
+            self.upload()
         return self
 
     # ---- lifecycle ----

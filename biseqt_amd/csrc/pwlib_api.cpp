@@ -167,6 +167,7 @@ struct pw_batch {
   int64_t cells = 0, alg_bytes = 0;
   // device
   uint8_t* d_arena = nullptr; uint64_t arena_bytes = 0;
+  bool arena_shared = false;             // PW_FLAG_SHARED_ARENA: d_arena belongs to the caller (pw_batch_share_arena)
   pw::PairDesc* d_pairs = nullptr;
   uint32_t* d_masks = nullptr; uint64_t mask_words = 0; size_t masks_alloc = 0, arena_alloc = 0, pairs_alloc = 0, results_alloc = 0;
   void* d_hdump = nullptr; uint64_t h_elems = 0;
@@ -187,7 +188,7 @@ int batch_free_device(pw_batch* b) {
   // was launched on any stream still reads or writes them
   (void)hipDeviceSynchronize();
   for (auto& c : b->classes) if (c.d_order) (void)hipFree(c.d_order);
-  pool_give(b->device, b->d_arena, b->arena_alloc);
+  if (!b->arena_shared) pool_give(b->device, b->d_arena, b->arena_alloc);
   pool_give(b->device, b->d_pairs, b->pairs_alloc);
   pool_give(b->device, b->d_masks, b->masks_alloc);
   if (b->d_hdump) (void)hipFree(b->d_hdump);
@@ -417,7 +418,9 @@ int batch_build(pw_batch* b) {
   const double t_plan = tnow();
   HIP_TRY(hipSetDevice(b->device));
   b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
-  HIP_TRY(pool_alloc(b->device, (void**)&b->d_arena, b->arena_bytes + 16, &b->arena_alloc));   // kernels read whole dwords: slack past the last frame
+  b->arena_shared = (b->flags & PW_FLAG_SHARED_ARENA) != 0;
+  if (!b->arena_shared)
+    HIP_TRY(pool_alloc(b->device, (void**)&b->d_arena, b->arena_bytes + 16, &b->arena_alloc));   // kernels read whole dwords: slack past the last frame
   HIP_TRY(pool_alloc(b->device, (void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1), &b->pairs_alloc));
   HIP_TRY(pool_alloc(b->device, (void**)&b->d_masks, 4 * mask_words + 64, &b->masks_alloc));   // slack: the walker reads whole 16-byte groups
   HIP_TRY(pool_alloc(b->device, (void**)&b->d_results, sizeof(pw::Result) * std::max<int32_t>(b->n, 1), &b->results_alloc));
@@ -671,7 +674,24 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   return name;
 }
 
+void* pw_arena_upload(int device, const uint8_t* host, uint64_t bytes) {
+  void* p = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes + 16) != hipSuccess) { (void)hipGetLastError(); fail("pw_arena_upload: allocation failed"); return nullptr; }
+  if (hipMemset((uint8_t*)p + bytes, 0, 16) != hipSuccess || (bytes && hipMemcpy(p, host, bytes, hipMemcpyHostToDevice) != hipSuccess)) {
+    (void)hipGetLastError(); (void)hipFree(p); fail("pw_arena_upload: copy failed"); return nullptr;
+  }
+  return p;
+}
+void pw_arena_free(int device, void* p) { if (p) { (void)hipSetDevice(device); (void)hipFree(p); } }
+int pw_batch_share_arena(pw_batch* b, void* dev) {
+  if (!b->arena_shared) return fail("pw_batch_share_arena: the batch was not created with PW_FLAG_SHARED_ARENA");
+  if (!dev) return fail("pw_batch_share_arena: null arena");
+  b->d_arena = (uint8_t*)dev;
+  return 0;
+}
+
 int pw_batch_upload_arena(pw_batch* b, const uint8_t* host, uint64_t bytes) {
+  if (b->arena_shared) return fail("the batch shares a caller-owned arena (PW_FLAG_SHARED_ARENA): nothing to upload");
   if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
   HIP_TRY(hipSetDevice(b->device));
   if (bytes) HIP_TRY(hipMemcpy(b->d_arena, host, bytes, hipMemcpyHostToDevice));
@@ -688,6 +708,7 @@ void* pw_host_alloc(uint64_t bytes) {
 void pw_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int pw_batch_upload_arena_async(pw_batch* b, const uint8_t* host, uint64_t bytes, void* stream) {
+  if (b->arena_shared) return fail("the batch shares a caller-owned arena (PW_FLAG_SHARED_ARENA): nothing to upload");
   if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
   HIP_TRY(hipSetDevice(b->device));
   if (bytes) HIP_TRY(hipMemcpyAsync(b->d_arena, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -706,6 +727,7 @@ int pw_batch_transcripts_async(pw_batch* b, uint8_t* out, void* stream) {
 
 int pw_batch_solve(pw_batch* b, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (b->arena_shared && !b->d_arena) return fail("pw_batch_solve: the batch was created with PW_FLAG_SHARED_ARENA and has no arena yet");
   HIP_TRY(hipSetDevice(b->device));
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_fill0, st));
   int rc = b->variant == pw::VAR_FAST16 ? launch_packed_fill(b, st)

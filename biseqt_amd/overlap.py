@@ -150,6 +150,45 @@ def overlap_all_pairs(reads, wordlen, alphabet, g_max, sensitivity, device=0, ma
     return dict(zip(plist, res))
 
 
+def aligned_batches(arena, offs, lens, pidx, dr, alphabet_len, device=0, max_cells=2 * 10 ** 10, flags=0, **kw):
+    """Banded overlap alignment of the read pairs ``pidx`` (read indices into the packed ``arena``, :func:`pack_reads`)
+    with bands ``dr``, in batches of at most ``max_cells`` cells.  The reads go to the device ONCE (``DeviceArena``) and
+    every batch refers to that copy; while one batch runs on the device the next one is planned on the host
+    (``pw_batch_create`` is host work: band clamps, kernel geometry, descriptors).  Yields ``(start, stop, batch)`` with
+    the batch solved, traced back and synchronised; the batch is destroyed when the generator moves on."""
+    from .batch import DeviceArena
+    pidx = np.ascontiguousarray(pidx, np.int64).reshape(-1, 2)
+    dr = np.ascontiguousarray(dr, np.int64).reshape(-1, 2)
+    cells = (dr[:, 1] - dr[:, 0] + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
+    bounds, start = [], 0
+    csum = np.cumsum(cells)
+    while start < len(pidx):
+        base = csum[start - 1] if start else 0
+        stop = max(start + 1, int(np.searchsorted(csum, base + max_cells, 'right')))
+        bounds.append((start, stop)); start = stop
+
+    def create(lo, hi):
+        return BatchAligner.from_arena(arena, offs, lens, pidx[lo:hi], dr[lo:hi], device_arena=dev, alnmode=W.BANDED_MODE,
+                                       alntype=W.B_OVERLAP, alphabet_len=alphabet_len, device=device, flags=flags, **kw)
+
+    with DeviceArena(arena, device) as dev:
+        cur = nxt = None
+        try:
+            nxt = create(*bounds[0]) if bounds else None
+            for q, (lo, hi) in enumerate(bounds):
+                cur, nxt = nxt, None
+                cur.solve(); cur.traceback()                       # asynchronous: the device is busy from here ...
+                if q + 1 < len(bounds):
+                    nxt = create(*bounds[q + 1])                   # ... while the next batch is planned
+                cur.sync()
+                yield lo, hi, cur
+                cur.close(); cur = None
+        finally:
+            for b in (cur, nxt):
+                if b is not None:
+                    b.close()
+
+
 def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, max_cells=2 * 10 ** 10, want_transcripts=True,
                        **aligner_kw):
     """Banded overlap alignment (``B_OVERLAP``) of every pair whose band has ``p >= p_min``; the ``diag_range`` is the
@@ -176,21 +215,14 @@ def overlap_alignments(reads, pairs, bands, alphabet, p_min=0., device=0, max_ce
     kw.update(aligner_kw)
     pidx = np.array([pairs[q] for q in sel], np.int64)
     dr = np.array(dr, np.int64)
-    cells = (dr[:, 1] - dr[:, 0] + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
-    start = 0
-    while start < len(sel):
-        csum = np.cumsum(cells[start:])
-        stop = start + max(1, int(np.searchsorted(csum, max_cells, 'right')))
-        with BatchAligner.from_arena(arena, offs, lens, pidx[start:stop], dr[start:stop], alnmode=W.BANDED_MODE,
-                                     alntype=W.B_OVERLAP, alphabet_len=len(alphabet), device=device, **kw) as b:
-            res = b.run()
-            txs = b.transcripts(res) if want_transcripts else [None] * (stop - start)
+    for start, stop, b in aligned_batches(arena, offs, lens, pidx, dr, len(alphabet), device=device, max_cells=max_cells, **kw):
+        res = b.results()
+        txs = b.transcripts(res) if want_transcripts else [None] * (stop - start)
         for k in range(stop - start):
             if res['opt_i'][k] < 0:
                 continue
             out[sel[start + k]] = dict(score=float(res['score'][k]), transcript=txs[k], origin_start=int(res['origin_idx'][k]),
                                        mutant_start=int(res['mutant_idx'][k]), diag_range=(int(dr[start + k, 0]), int(dr[start + k, 1])))
-        start = stop
     return out
 
 

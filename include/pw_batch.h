@@ -64,6 +64,7 @@ typedef struct {
 #define PW_FLAG_NO_PACKED16 16   /* never use the packed 16-bit steady-phase kernel (testing / A-B) */
 #define PW_FLAG_FORCE_TILED 32   /* run every pair through the time-blocked tiled kernel (testing) */
 #define PW_FLAG_FORCE_STRIP 64   /* run every pair that the strip pipeline supports through it (testing) */
+#define PW_FLAG_SHARED_ARENA 128 /* the batch owns no arena: pw_batch_share_arena gives it a caller-owned device copy */
 
 const char* pw_last_error(void);
 int pw_device_count(void);
@@ -94,6 +95,13 @@ const char* pw_batch_kernel_name(const pw_batch* b);                         /* 
 
 int pw_batch_upload_arena(pw_batch* b, const uint8_t* host_arena, uint64_t bytes);   /* synchronous H2D */
 void* pw_batch_arena_device(pw_batch* b);
+/* One device copy of an arena for MANY batches (overlap pipelines: every read takes part in dozens of pairs, the pairs are
+ * solved in several batches): pw_arena_upload returns a device copy of `bytes` bytes (+ the slack the kernels read), owned
+ * by the caller until pw_arena_free; a batch created with PW_FLAG_SHARED_ARENA reads its frames from the copy it is given
+ * by pw_batch_share_arena (at least the batch's arena_bytes long) instead of allocating and uploading its own. */
+void* pw_arena_upload(int device, const uint8_t* host_arena, uint64_t bytes);
+void pw_arena_free(int device, void* dev_arena);
+int pw_batch_share_arena(pw_batch* b, void* dev_arena);
 /* Pinned host memory for the asynchronous transfers below (hipHostMalloc / hipHostFree). */
 void* pw_host_alloc(uint64_t bytes);
 void pw_host_free(void* p);

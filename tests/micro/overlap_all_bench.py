@@ -59,22 +59,13 @@ def main():
     dr = np.stack([lo, hi], axis=1)
     cells = (hi - lo + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
     t5 = time.perf_counter()
-    start, dev_ms, tot_cells, nb, score_sum = 0, 0.0, 0, 0, 0.0
-    while start < len(sel):
-        stop = start + max(1, int(np.searchsorted(np.cumsum(cells[start:]), int(os.environ.get('OV_MAX_CELLS', 2 * 10 ** 10)), 'right')))
-        ta = time.perf_counter()
-        with BatchAligner.from_arena(arena, offs, lens, pidx[start:stop], dr[start:stop], alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP,
-                                     alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2,
-                                     flags=W.PW_FLAG_PROFILE) as b:
-            tb = time.perf_counter()
-            b.solve(); b.traceback(); b.sync()
-            tc = time.perf_counter()
-            res = b.results()
-            if os.environ.get('OV_VERBOSE'):
-                print('    batch of %d pairs: create %.2f s, run %.2f s, results %.2f s' % (stop - start, tb - ta, tc - tb, time.perf_counter() - tc), flush=True)
-            dev_ms += b.fill_ms() + b.trace_ms(); tot_cells += b.cells; nb += 1; score_sum += float(res['score'].sum())
-            kname = b.kernel_name
-        start = stop
+    dev_ms, tot_cells, nb, score_sum, kname = 0.0, 0, 0, 0.0, ''
+    from biseqt_amd.overlap import aligned_batches
+    for start, stop, b in aligned_batches(arena, offs, lens, pidx, dr, 4, max_cells=int(os.environ.get('OV_MAX_CELLS', 2 * 10 ** 10)),
+                                          flags=W.PW_FLAG_PROFILE, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2):
+        res = b.results()
+        dev_ms += b.fill_ms() + b.trace_ms(); tot_cells += b.cells; nb += 1; score_sum += float(res['score'].sum())
+        kname = b.kernel_name
     t6 = time.perf_counter()
     if len(sel):
         print('  banded overlap alignment of %d pairs in %d batches: %.3g cells, device %.1f ms = %.0f GCUPS (%s); wall %.2f s '
