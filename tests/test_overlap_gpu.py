@@ -229,3 +229,42 @@ def test_all_pairs_job_every_alignment_rescored():
         start = stop
     assert n_checked == len(sel) and n_checked > 30000
     assert all('k_fill16' in kn for kn in kernels), kernels
+
+
+def test_shared_device_arena_and_pipelined_batches_equal_private_copies():
+    """One device copy of the reads for all batches of a job (pw_arena_upload / PW_FLAG_SHARED_ARENA) and the pipelined
+    batch loop (the next batch is planned while one runs) return what batches with their own arena copy return; a batch
+    created for a shared arena refuses to run without one and refuses an upload."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner, DeviceArena, pack_reads
+    from biseqt_amd.overlap import aligned_batches
+    rng = synth.rng_for(4242)
+    genome = synth.rand_seqs(rng, 1, 30000)[0]
+    reads = []
+    for _ in range(120):
+        a = int(rng.integers(0, 30000 - 1500))
+        reads.append(synth.mutate(rng, genome[a:a + int(rng.integers(600, 1500))], 0.03, 0.01, 0.5))
+    arena, offs, lens = pack_reads(reads)
+    pidx = np.array([(i, j) for i in range(120) for j in range(i + 1, 120) if (i * 7 + j) % 9 == 0], np.int64)
+    dr = np.stack([np.maximum(-lens[pidx[:, 1]].astype(np.int64), -60), np.minimum(lens[pidx[:, 0]].astype(np.int64), 60)], axis=1)
+    kw = dict(alnmode=W.BANDED_MODE, alntype=W.B_OVERLAP, alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
+    with BatchAligner.from_arena(arena, offs, lens, pidx, dr, **kw) as b:
+        ref = b.run().copy()
+        ref_tx = b.transcripts(ref)
+    got, got_tx, nb = [], [], 0
+    for start, stop, b in aligned_batches(arena, offs, lens, pidx, dr, 4, max_cells=3 * 10 ** 6, match_score=1, mismatch_score=-3,
+                                          go_score=-5, ge_score=-2):
+        res = b.results()
+        got.append(res.copy()); got_tx.extend(b.transcripts(res)); nb += 1
+    assert nb >= 3
+    got = np.concatenate(got)
+    assert (got == ref).all() and got_tx == ref_tx
+    with DeviceArena(arena) as dev:
+        b = BatchAligner.from_arena(arena, offs, lens, pidx[:50], dr[:50], device_arena=dev, **kw)
+        try:
+            with pytest.raises(RuntimeError):
+                b.upload()
+            assert (b.run() == ref[:50]).all()
+        finally:
+            b.close()
