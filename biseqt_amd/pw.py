@@ -190,7 +190,9 @@ class Alignment(object):
         assert isinstance(origin, Sequence) and isinstance(mutant, Sequence)
         assert origin.alphabet == mutant.alphabet
         self.alphabet = origin.alphabet
-        assert all(c in 'MSID' for c in transcript)
+        transcript = str(transcript)
+        # (counted with str.count, not a Python loop: transcripts of long alignments have 10^4 - 10^5 ops)
+        assert sum(transcript.count(c) for c in 'MSID') == len(transcript)
         assert len(transcript) > 0
         origin_end = origin_start + self.projected_len(transcript, on='origin')
         mutant_end = mutant_start + self.projected_len(transcript, on='mutant')
@@ -224,6 +226,8 @@ class Alignment(object):
         (``pw.py:367-389``)."""
         assert on in ['origin', 'mutant']
         ops = 'MSD' if on == 'origin' else 'MSI'
+        if isinstance(transcript, str):
+            return sum(transcript.count(op) for op in ops)
         return sum(int(op in ops) for op in transcript)
 
     def calculate_score(self, subst_scores, go_score, ge_score):
@@ -248,17 +252,14 @@ class Alignment(object):
 
     def truncate_to_match(self):
         """The sub-alignment between the first and the last ``M``, or None (``pw.py:430-448``)."""
-        tx_start = 0
         origin_start, mutant_start = self.origin_start, self.mutant_start
-        tx_end = len(self.transcript) - 1
-        while self.transcript[tx_start] != 'M':
-            if self.transcript[tx_start] in 'DS':
-                origin_start += 1
-            if self.transcript[tx_start] in 'IS':
-                mutant_start += 1
-            tx_start += 1
-        while self.transcript[tx_end] != 'M':
-            tx_end -= 1
+        tx_start, tx_end = self.transcript.find('M'), self.transcript.rfind('M')
+        if tx_start < 0:
+            # the reference's loop runs off the end of the transcript here (IndexError, pw.py:436): same failure
+            raise IndexError('string index out of range')
+        head = self.transcript[:tx_start]
+        origin_start += head.count('D') + head.count('S')
+        mutant_start += head.count('I') + head.count('S')
         if tx_start < tx_end:
             return Alignment(self.origin, self.mutant, self.transcript[tx_start:tx_end + 1],
                              origin_start=origin_start, mutant_start=mutant_start)
