@@ -598,13 +598,24 @@ PW_FN void strip_walk(const StripTraceParams& p, uint32_t* win) {
       nibj = (word >> (4 * (7 - (kj & 7)))) & 15u;
     }
     const uint64_t pure = P::ballot(inwin && (nibj & 7u) == 0u);
-    int run = (int)__builtin_ctzll(~pure | ((uint64_t)1 << 63));   // pure-M cells in a row, starting with this one
+    const uint64_t seen = P::ballot(inwin);
+    const int run0 = (int)__builtin_ctzll(~pure | ((uint64_t)1 << 63));   // pure-M cells in a row, starting with this one
     const int lim = x < y ? x : y;                                  // a diagonal move needs x >= 1 and y >= 1
-    run = run < lim ? run : lim;
+    int run = run0 < lim ? run0 : lim;
     run = run < pos ? run : pos;
     if (run > 0) {
       if (lane < run) tx[pos - 1 - lane] = (uint8_t)'X';
       pos -= run; nms += run; x -= run; y -= run; prev = 3;
+      // the cell that ends the run is lane `run`'s: if this window shows it, take its op in the same round (after an M the
+      // rule is "first kept op", and a cell that is not pure M keeps B, D or I)
+      if (run == run0 && run0 < 63 && ((seen >> run) & 1u) && pos > 0) {      // (63 is the ballot's sentinel, not a break)
+        const int op = pw_first_op(P::readlane(nibj, run));
+        if (op == 0) break;
+        if (lane == 0) tx[pos - 1] = (uint8_t)(op == 1 ? 'D' : 'I');
+        pos -= 1;
+        x -= (op != 2); y -= (op != 1);
+        prev = op;
+      }
       continue;
     }
     // ---- the current cell breaks the run: the predecessor rule on its mask
