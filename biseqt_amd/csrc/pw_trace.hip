@@ -16,9 +16,16 @@ __global__ __launch_bounds__(64) void k_trace(const TraceParams p, const int wal
   if ((int)threadIdx.x < walkers && pair < p.npairs) trace_walk(p, pair, win[threadIdx.x]);
 }
 
-// K4b, wave-parallel: one wavefront per pair, 64 transcript positions per pass.  The (x, y) each
-// position refers to is the start cell plus the number of origin- / mutant-consuming ops in front of it:
-// a ballot and a popcount below the lane.
+// K4b, wave-parallel: 64 transcript positions per pass.  The (x, y) each position refers to is the start cell plus the
+// number of origin- / mutant-consuming ops in front of it: a ballot and a popcount below the lane.  A long transcript (a
+// strip-pipeline pair: 10^5 ops) is cut into gridDim.y segments, one wavefront each; a segment's start cell is the
+// alignment's start plus the ops in front of the segment, which the wavefront counts itself (bytes equal to 'I' / 'D',
+// four per lane and pass) -- no pass over the segments, no second kernel.
+__device__ inline uint32_t bytes_equal(uint32_t w, uint32_t c4) {      // 0x80 in every byte of w that equals the byte of c4
+  const uint32_t v = w ^ c4;
+  const uint32_t t = (v & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+  return ~(t | v | 0x7f7f7f7fu);
+}
 __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
   const int pair = (int)blockIdx.x;
   const PairDesc& pd = p.pairs[pair];
@@ -30,10 +37,32 @@ __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
   uint8_t* tx = p.transcripts + pd.tx_off + pd.tx_cap - r.tx_len;
   const int lane = (int)(threadIdx.x & 63u);
   const unsigned long long below = (1ull << lane) - 1ull;
+  const int nseg = (int)gridDim.y, seg = (int)blockIdx.y;
+  const int seglen = ((r.tx_len + nseg - 1) / nseg + 63) & ~63;
+  const int s0 = seg * seglen;
+  if (s0 >= r.tx_len) return;
+  const int s1 = r.tx_len < s0 + seglen ? r.tx_len : s0 + seglen;
   int x = r.origin_idx, y = r.mutant_idx;
-  for (int k0 = 0; k0 < r.tx_len; k0 += 64) {
+  if (s0 > 0) {
+    // ops in [0, s0): every op but I consumes an origin letter, every op but D a mutant letter
+    int nI = 0, nD = 0;
+    const int head = (int)((4u - (uint32_t)((uintptr_t)tx & 3u)) & 3u);       // bytes up to the first aligned dword
+    if (lane < head && lane < s0) { nI += tx[lane] == 'I'; nD += tx[lane] == 'D'; }
+    const int nwords = s0 > head ? (s0 - head) >> 2 : 0;
+    const uint32_t* tw = (const uint32_t*)(tx + head);
+    for (int q = lane; q < nwords; q += 64) {
+      const uint32_t w = tw[q];
+      nI += __popc(bytes_equal(w, 0x49494949u)); nD += __popc(bytes_equal(w, 0x44444444u));
+    }
+    const int tail0 = head + 4 * nwords;
+    if (tail0 + lane < s0) { nI += tx[tail0 + lane] == 'I'; nD += tx[tail0 + lane] == 'D'; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { nI += __shfl_xor(nI, off, 64); nD += __shfl_xor(nD, off, 64); }
+    x += s0 - nI; y += s0 - nD;
+  }
+  for (int k0 = s0; k0 < s1; k0 += 64) {
     const int k = k0 + lane;
-    const uint8_t ch = k < r.tx_len ? tx[k] : (uint8_t)0;
+    const uint8_t ch = k < s1 ? tx[k] : (uint8_t)0;
     const bool isx = ch == 'X';
     const unsigned long long bo = __ballot(isx || ch == 'D'), bm = __ballot(isx || ch == 'I');
     if (isx) {
@@ -72,7 +101,8 @@ hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
   hipLaunchKernelGGL(k_trace, dim3((unsigned)((p.npairs + walkers - 1) / walkers)), dim3(64), 0, st, p, walkers);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_trace_fixup, dim3((unsigned)p.npairs), dim3(64), 0, st, p);
+  // (segments: 1 for batches of short transcripts; with strip-pipeline pairs in the batch their transcripts are cut)
+  hipLaunchKernelGGL(k_trace_fixup, dim3((unsigned)p.npairs, (unsigned)(p.fix_segments > 0 ? p.fix_segments : 1)), dim3(64), 0, st, p);
   return hipGetLastError();
 }
 

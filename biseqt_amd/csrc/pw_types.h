@@ -118,6 +118,7 @@ struct TraceParams {
   int32_t gosign;             // sign of the gap-open score: -1, 0, +1
   int32_t banded;             // table coordinates are (d - dmin, a)
   const int32_t* ends;        // optional explicit end cells (table i,j pairs) overriding results[].opt_*
+  int32_t fix_segments;       // wavefronts per transcript in the fix-up pass (0 / 1: one)
 };
 
 // ---- mask plane addressing (shared by fill, traceback and tests) -------------------------------

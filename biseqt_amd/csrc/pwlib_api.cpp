@@ -744,6 +744,12 @@ static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
   p.pairs = b->d_pairs; p.arena = b->d_arena; p.masks = b->d_masks; p.results = b->d_results;
   p.transcripts = b->d_tx; p.npairs = b->n; p.gosign = b->gosign;
   p.banded = b->mode == pw::BANDED_MODE; p.ends = d_ends;
+  // long transcripts (strip-pipeline pairs) are fixed up by several wavefronts each: ~2000 ops per segment
+  if (!b->strips.empty()) {
+    int64_t longest = 0;
+    for (int32_t k : b->strips) longest = std::max<int64_t>(longest, b->descs[k].tx_cap);
+    p.fix_segments = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, longest / 2048));
+  }
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_tr0, st));
   for (int32_t k : b->strips) {        // strip-layout pairs: one wavefront each (before the fix-up pass below)
     const pw::PairDesc& d = b->descs[k];
