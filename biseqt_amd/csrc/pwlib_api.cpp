@@ -15,6 +15,7 @@
 #include <string>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/pw_batch.h"
@@ -1039,10 +1040,24 @@ intpair dptable_solve(dptable* T) {
     if (pw_batch_table(h->batch, 0, table, h->ncells) != 0) { fprintf(stderr, "pwlib: %s\n", pw_last_error()); free(table); return none; }
     t_plane = now() - t_b;
     const int mins_cd = prob->max_new_mins;
-    for (int64_t c = 0; c < h->ncells; c++) {
-      alnchoice* ch = &h->choice_slab[c];
-      ch->op = 0; ch->score = table[c]; ch->base = NULL; ch->mins_cd = mins_cd; ch->cur_min = 0;
-      h->cell_slab[c].num_choices = 1; h->cell_slab[c].choices = ch;
+    // 48 bytes per cell of freshly allocated host memory: first touch and stores are spread over a few threads
+    auto fill_cells = [&](int64_t c0, int64_t c1) {
+      for (int64_t c = c0; c < c1; c++) {
+        alnchoice* ch = &h->choice_slab[c];
+        ch->op = 0; ch->score = table[c]; ch->base = NULL; ch->mins_cd = mins_cd; ch->cur_min = 0;
+        h->cell_slab[c].num_choices = 1; h->cell_slab[c].choices = ch;
+      }
+    };
+    const int nth = h->ncells >= (1 << 16) ? std::max(1, std::min(8, (int)std::thread::hardware_concurrency())) : 1;
+    if (nth <= 1) fill_cells(0, h->ncells);
+    else {
+      std::vector<std::thread> th;
+      const int64_t per = (h->ncells + nth - 1) / nth;
+      for (int t = 0; t < nth; t++) {
+        const int64_t c0 = t * per, c1 = std::min<int64_t>(h->ncells, c0 + per);
+        if (c0 < c1) th.emplace_back(fill_cells, c0, c1);
+      }
+      for (auto& t : th) t.join();
     }
     free(table);
   } else if (res.opt_i >= 0 && res.opt_j >= 0) {
