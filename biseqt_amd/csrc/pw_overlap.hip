@@ -109,6 +109,12 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
   __shared__ uint32_t s_sum[256];
   __shared__ double s_w[256];
   __shared__ int s_d[256], s_cnt[256];
+  // the occupied diagonals of the pair, in no particular order: the seeds of a true overlap sit on a few dozen neighbouring
+  // diagonals, i.e. in the chunks of one or two threads -- evaluating them where they are found left 254 threads idle
+  // (0.5 ms per pair); listed first, they are dealt round-robin
+  constexpr int kMaxOcc = 8192;
+  __shared__ int s_occ[kMaxOcc];
+  __shared__ int s_nocc;
   const int p = (int)blockIdx.x, tid = (int)threadIdx.x;
   const DPair pr = pairs[p];
   const int ls = pr.s_len, lt = pr.t_len, nd = ls + lt + 1;
@@ -131,31 +137,56 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
     s_sum[tid] += v;
     __syncthreads();
   }
+  if (tid == 0) s_nocc = 0;
+  __syncthreads();
   uint32_t run = tid ? s_sum[tid - 1] : 0u;
-  for (int dd = b; dd < e; dd++) { run += h[dd]; h[dd] = run; }
+  for (int dd = b; dd < e; dd++) {
+    const uint32_t v = h[dd];
+    run += v; h[dd] = run;
+    if (v) { const int q = atomicAdd(&s_nocc, 1); if (q < kMaxOcc) s_occ[q] = dd; }
+  }
   __threadfence_block();
   __syncthreads();
+  const int nocc = s_nocc;
+  const bool listed = nocc <= kMaxOcc;                 // else: every thread walks its own chunk (as before)
   auto pre = [&](int dd) -> uint32_t { return dd < 0 ? 0u : h[dd < nd ? dd : nd - 1]; };
   // neighbours of a seed on diagonal d and the score of its band
   auto eval = [&](int d, int& n, int& L, int& r) -> double {
     L = ov_len(d, ls, lt, c.q); r = ov_rad(L, c.C);
     const double x = (double)d / (double)r;
-    int lo = -lt, hi = d;                              // smallest d' with x - x(d') <= 1
-    while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (!(x - ov_x(mid, ls, lt, c) <= 1.0)) lo = mid + 1; else hi = mid; }
-    const int first = lo;
-    lo = d; hi = ls;                                   // largest d' with x(d') - x <= 1
-    while (lo < hi) { const int mid = lo + ((hi - lo + 1) >> 1); if (ov_x(mid, ls, lt, c) - x <= 1.0) lo = mid; else hi = mid - 1; }
+    // The window of diagonals within 1 of d on the axis d / r(d).  Both predicates are monotone in d' (what the binary
+    // searches of the first version relied on), so the same two boundaries are found by walking from a guess -- d -+ r,
+    // where they are unless r(d') changes in between: a handful of evaluations of x(d') instead of 2 x 14.
+    int first = d - r < -lt ? -lt : d - r;             // smallest d' in [-lt, d] with x - x(d') <= 1
+    if (x - ov_x(first, ls, lt, c) <= 1.0) { while (first > -lt && x - ov_x(first - 1, ls, lt, c) <= 1.0) first--; }
+    else { do first++; while (first < d && !(x - ov_x(first, ls, lt, c) <= 1.0)); }
+    int lo = d + r > ls ? ls : d + r;                  // largest d' in [d, ls] with x(d') - x <= 1
+    if (ov_x(lo, ls, lt, c) - x <= 1.0) { while (lo < ls && ov_x(lo + 1, ls, lt, c) - x <= 1.0) lo++; }
+    else { do lo--; while (lo > d && !(ov_x(lo, ls, lt, c) - x <= 1.0)); }
     n = (int)(pre(lo + lt) - pre(first + lt - 1)) - 1;
     const long long area = 2ll * r * L;
     return ((double)(n + 1) - (double)area * c.p0) / (double)L;
   };
   // ---- pass 1: the best occupied diagonal (largest w, then smallest d) ----
   double bw = 0.0; int bd = 0x7fffffff;
-  for (int dd = b; dd < e; dd++) {
-    if (pre(dd) == pre(dd - 1)) continue;
-    int n, L, r;
-    const double w = eval(dd - lt, n, L, r);
-    if (bd == 0x7fffffff || w > bw) { bw = w; bd = dd - lt; }
+  constexpr int kKeep = 4;                             // scores of this thread's first diagonals, kept for pass 2
+  double wkeep[kKeep];
+  if (listed) {
+    int it = 0;
+    for (int q = tid; q < nocc; q += 256, it++) {
+      const int d = s_occ[q] - lt;
+      int n, L, r;
+      const double w = eval(d, n, L, r);
+      if (it < kKeep) wkeep[it] = w;
+      if (bd == 0x7fffffff || w > bw || (w == bw && d < bd)) { bw = w; bd = d; }
+    }
+  } else {
+    for (int dd = b; dd < e; dd++) {
+      if (pre(dd) == pre(dd - 1)) continue;
+      int n, L, r;
+      const double w = eval(dd - lt, n, L, r);
+      if (bd == 0x7fffffff || w > bw) { bw = w; bd = dd - lt; }
+    }
   }
   s_w[tid] = bw; s_d[tid] = bd;
   __syncthreads();
@@ -173,11 +204,20 @@ __global__ __launch_bounds__(256) void k_band_select(const DPair* __restrict__ p
   int ties = 0;
   const double wcap = wbest >= 1.0 ? 1.0 : wbest;           // p = min(w^(1/k), 1): everything at or above 1 ties
   const double thr = wcap - fabs(wcap) * 1e-9;
-  for (int dd = b; dd < e; dd++) {
-    if (pre(dd) == pre(dd - 1)) continue;
-    int n, L, r;
-    const double w = eval(dd - lt, n, L, r);
-    ties += (wbest <= 0.0 || w >= thr) ? 1 : 0;
+  if (listed) {
+    int it = 0;
+    for (int q = tid; q < nocc; q += 256, it++) {
+      int n, L, r;
+      const double w = it < kKeep ? wkeep[it] : eval(s_occ[q] - lt, n, L, r);
+      ties += (wbest <= 0.0 || w >= thr) ? 1 : 0;
+    }
+  } else {
+    for (int dd = b; dd < e; dd++) {
+      if (pre(dd) == pre(dd - 1)) continue;
+      int n, L, r;
+      const double w = eval(dd - lt, n, L, r);
+      ties += (wbest <= 0.0 || w >= thr) ? 1 : 0;
+    }
   }
   s_cnt[tid] = ties;
   __syncthreads();
@@ -265,22 +305,24 @@ __global__ __launch_bounds__(256) void k_cand_pairs(const uint64_t* __restrict__
   pa[u] = (int32_t)a; pb[u] = (int32_t)b;
 }
 constexpr int kSmallPair = 64;     // pairs with at most this many seeds are scored by one wavefront, without a histogram
+constexpr int kMediumPair = 2048;  // all-pairs path: up to this many seeds by one workgroup from the seed list (k_band_medium)
 __global__ __launch_bounds__(256) void k_pair_hsize(const uint64_t* __restrict__ ukeys, const unsigned long long* __restrict__ cnt,
                                                     int64_t np, uint64_t nreads, const int32_t* __restrict__ rlen,
-                                                    uint64_t* __restrict__ hsize) {
+                                                    uint64_t* __restrict__ hsize, int sparse_max) {
   const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (u >= np) return;
-  hsize[u] = cnt[u] <= (unsigned long long)kSmallPair ? 0ull
+  hsize[u] = cnt[u] <= (unsigned long long)sparse_max ? 0ull
                                                       : (uint64_t)rlen[ukeys[u] / nreads] + (uint64_t)rlen[ukeys[u] % nreads] + 1;
 }
 // seeds [s0, s1) belong to the pairs [u0, u1) of this chunk; hbase is relative to the chunk's first histogram entry
 __global__ __launch_bounds__(256) void k_scatter_hist(const int32_t* __restrict__ dval, int64_t s0, int64_t s1,
                                                       const uint64_t* __restrict__ soff, int64_t u0, int64_t u1,
-                                                      const DPair* __restrict__ pairs, uint64_t hchunk0, uint32_t* __restrict__ hist) {
+                                                      const DPair* __restrict__ pairs, uint64_t hchunk0, uint32_t* __restrict__ hist,
+                                                      int sparse_max) {
   const int64_t o = s0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (o >= s1) return;
   const int64_t u = u0 + ub_u64(soff + u0, u1 - u0, (uint64_t)o) - 1;
-  if ((u + 1 < u1 ? soff[u + 1] : (uint64_t)s1) - soff[u] <= (uint64_t)kSmallPair) return;     // no histogram for small pairs
+  if ((u + 1 < u1 ? soff[u + 1] : (uint64_t)s1) - soff[u] <= (uint64_t)sparse_max) return;     // no histogram for sparse pairs
   const DPair pr = pairs[u];
   atomicAdd(&hist[pr.hbase - hchunk0 + (uint64_t)(dval[o] + pr.t_len)], 1u);
 }
@@ -345,6 +387,127 @@ __global__ __launch_bounds__(256) void k_band_small(const DPair* __restrict__ pa
     o.n_seeds = ns; o.w_best = bw; o.d_best = bd; o.n_best = nb; o.r_best = rb; o.len_best = Lb;
     o.band_best = __popcll(band_b); o.tie = __popcll(tie_mask);
     o.d_first = d0; o.n_first = n0; o.r_first = r0; o.len_first = L0; o.band_first = __popcll(band_f);
+    out[u] = o;
+  }
+}
+
+// L, r and the window [first, last] of diagonals within 1 of d on the axis d / r(d): the values k_band_select's eval() uses
+__device__ __forceinline__ void ov_window(int d, int ls, int lt, BandConst c, int& L, int& r, int& first, int& last) {
+  L = ov_len(d, ls, lt, c.q); r = ov_rad(L, c.C);
+  const double x = (double)d / (double)r;
+  first = d - r < -lt ? -lt : d - r;
+  if (x - ov_x(first, ls, lt, c) <= 1.0) { while (first > -lt && x - ov_x(first - 1, ls, lt, c) <= 1.0) first--; }
+  else { do first++; while (first < d && !(x - ov_x(first, ls, lt, c) <= 1.0)); }
+  last = d + r > ls ? ls : d + r;
+  if (ov_x(last, ls, lt, c) - x <= 1.0) { while (last < ls && ov_x(last + 1, ls, lt, c) - x <= 1.0) last++; }
+  else { do last--; while (last > d && !(ov_x(last, ls, lt, c) - x <= 1.0)); }
+}
+
+// K8e: a pair with 65 .. kMediumPair seeds is scored by ONE workgroup straight from its seed list in LDS (all-pairs path):
+// the same L, r, window, n, w per occupied diagonal as k_band_select -- the neighbour count by a loop over the list instead
+// of a prefix-summed histogram of |S| + |T| + 1 counters per pair (10 001 for 5 kb reads: reading and summing them was the
+// bulk of the dense kernel's time, for the ~250 seeds of a true overlap).  The first seed of every occupied diagonal
+// represents it.
+__global__ __launch_bounds__(256) void k_list_medium(const unsigned long long* __restrict__ cnt, int64_t np, unsigned long long* __restrict__ n_list,
+                                                     int64_t* __restrict__ list) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= np) return;
+  if (cnt[u] > (unsigned long long)kSmallPair && cnt[u] <= (unsigned long long)kMediumPair) list[atomicAdd(n_list, 1ull)] = u;
+}
+__global__ __launch_bounds__(256) void k_band_medium(const DPair* __restrict__ pairs, const int64_t* __restrict__ list,
+                                                     const uint64_t* __restrict__ soff, const unsigned long long* __restrict__ cnt,
+                                                     const int32_t* __restrict__ dval, const int32_t* __restrict__ d_first, BandConst c,
+                                                     pw_overlap_band* __restrict__ out) {
+  constexpr int PER = kMediumPair / 256;
+  __shared__ int s_dv[kMediumPair];
+  __shared__ double s_w[256];
+  __shared__ int s_d[256], s_cnt[256], s_b1[256], s_b2[256];
+  __shared__ int s_best[3], s_first[3];
+  const int64_t u = list[blockIdx.x];
+  const int tid = (int)threadIdx.x;
+  const int ns = (int)cnt[u];
+  const DPair pr = pairs[u];
+  const int ls = pr.s_len, lt = pr.t_len;
+  const uint64_t base = soff[u];
+  for (int l = tid; l < ns; l += 256) s_dv[l] = dval[base + (uint64_t)l];
+  __syncthreads();
+  const int d0 = d_first[u];
+  double wq[PER];
+  unsigned repmask = 0;
+  double bw = 0.0; int bd = 0x7fffffff;
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int l = tid + 256 * q;
+    wq[q] = 0.0;
+    if (l < ns) {
+      const int d = s_dv[l];
+      int L, r, first, last;
+      ov_window(d, ls, lt, c, L, r, first, last);
+      int n = -1; bool rp = true;
+      for (int j = 0; j < ns; j++) {
+        const int dj = s_dv[j];
+        n += (dj >= first && dj <= last) ? 1 : 0;
+        rp = rp && !(j < l && dj == d);
+      }
+      const double w = ((double)(n + 1) - (double)(2ll * r * L) * c.p0) / (double)L;
+      wq[q] = w;
+      if (rp) {
+        repmask |= 1u << q;
+        if (bd == 0x7fffffff || w > bw || (w == bw && d < bd)) { bw = w; bd = d; }
+      }
+      if (d == d0 && rp) { s_first[0] = n; s_first[1] = L; s_first[2] = r; }       // (one representative per diagonal)
+    }
+  }
+  s_w[tid] = bw; s_d[tid] = bd;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) {
+      const double ow = s_w[tid + off]; const int od = s_d[tid + off];
+      const bool have = s_d[tid] != 0x7fffffff, ohave = od != 0x7fffffff;
+      if (ohave && (!have || ow > s_w[tid] || (ow == s_w[tid] && od < s_d[tid]))) { s_w[tid] = ow; s_d[tid] = od; }
+    }
+    __syncthreads();
+  }
+  const double wbest = s_w[0]; const int dbest = s_d[0];
+  __syncthreads();
+  const double wcap = wbest >= 1.0 ? 1.0 : wbest;
+  const double thr = wcap - fabs(wcap) * 1e-9;
+  int ties = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) {
+    const int l = tid + 256 * q;
+    if (l < ns && (repmask >> q & 1u)) {
+      ties += (wbest <= 0.0 || wq[q] >= thr) ? 1 : 0;
+      if (s_dv[l] == dbest) {                                                       // the best diagonal's representative
+        int L, r, first, last;
+        ov_window(dbest, ls, lt, c, L, r, first, last);
+        int n = -1;
+        for (int j = 0; j < ns; j++) n += (s_dv[j] >= first && s_dv[j] <= last) ? 1 : 0;
+        s_best[0] = n; s_best[1] = L; s_best[2] = r;
+      }
+    }
+  }
+  s_cnt[tid] = ties;
+  __syncthreads();
+  const int rb = s_best[2], r0 = s_first[2];
+  int b1 = 0, b2 = 0;
+  for (int l = tid; l < ns; l += 256) {
+    const int d = s_dv[l];
+    b1 += (d >= dbest - rb && d <= dbest + rb) ? 1 : 0;
+    b2 += (d >= d0 - r0 && d <= d0 + r0) ? 1 : 0;
+  }
+  s_b1[tid] = b1; s_b2[tid] = b2;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (tid < off) { s_cnt[tid] += s_cnt[tid + off]; s_b1[tid] += s_b1[tid + off]; s_b2[tid] += s_b2[tid + off]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    pw_overlap_band o;
+    memset(&o, 0, sizeof o);
+    o.n_seeds = ns; o.w_best = wbest; o.d_best = dbest; o.n_best = s_best[0]; o.len_best = s_best[1]; o.r_best = s_best[2];
+    o.band_best = s_b1[0]; o.tie = s_cnt[0];
+    o.d_first = d0; o.n_first = s_first[0]; o.len_first = s_first[1]; o.r_first = s_first[2]; o.band_first = s_b2[0];
     out[u] = o;
   }
 }
@@ -509,31 +672,54 @@ int run_all_pairs(const uint8_t* d_arena, const uint64_t* read_off, const int32_
   if (tmp5.alloc(tb5)) return -1;
   OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)uc.p, (uint64_t*)soff.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
   hipLaunchKernelGGL(k_pair_hsize, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (const unsigned long long*)uc.p, (int64_t)NP, (uint64_t)R,
-                     (const int32_t*)drlen.p, (uint64_t*)hsize.p);
+                     (const int32_t*)drlen.p, (uint64_t*)hsize.p, kMediumPair);
   OV_CHECK(rocprim::exclusive_scan(tmp5.p, tb5, (const uint64_t*)hsize.p, (uint64_t*)hbase.p, (uint64_t)0, (size_t)NP, rocprim::plus<uint64_t>(), (hipStream_t) nullptr));
   hipLaunchKernelGGL(k_cand_pairs, gP, blk, 0, nullptr, (const uint64_t*)uk.p, (const uint64_t*)soff.p, (const int32_t*)dv.p, (int64_t)NP, (uint64_t)R,
                      (const uint64_t*)droff.p, (const int32_t*)drlen.p, (const uint64_t*)hbase.p, (DPair*)dpairs.p, (int32_t*)dfirst.p,
                      (int32_t*)dpa.p, (int32_t*)dpb.p);
   hipLaunchKernelGGL(k_band_small, dim3((unsigned)((NP * 64 + 255) / 256)), blk, 0, nullptr, (const DPair*)dpairs.p, (const uint64_t*)soff.p,
                      (const unsigned long long*)uc.p, (const int32_t*)dv.p, (const int32_t*)nullptr, (int64_t)NP, bc, (pw_overlap_band*)dout.p);
-  // chunks of pairs whose histograms fit 2^30 counters
-  std::vector<uint64_t> h_hbase((size_t)NP), h_soff((size_t)NP), h_hsize((size_t)NP);
+  // pairs with 65 .. kMediumPair seeds: one workgroup each, from the seed list
+  {
+    Buf mlist, mcount;
+    if (mlist.alloc(8 * (size_t)NP) || mcount.alloc(16)) return -1;
+    OV_CHECK(hipMemsetAsync(mcount.p, 0, 16, nullptr));
+    hipLaunchKernelGGL(k_list_medium, gP, blk, 0, nullptr, (const unsigned long long*)uc.p, (int64_t)NP, (unsigned long long*)mcount.p, (int64_t*)mlist.p);
+    unsigned long long NM = 0;
+    OV_CHECK(hipMemcpy(&NM, mcount.p, 8, hipMemcpyDeviceToHost));
+    if (NM) hipLaunchKernelGGL(k_band_medium, dim3((unsigned)NM), blk, 0, nullptr, (const DPair*)dpairs.p, (const int64_t*)mlist.p, (const uint64_t*)soff.p,
+                               (const unsigned long long*)uc.p, (const int32_t*)dv.p, (const int32_t*)dfirst.p, bc, (pw_overlap_band*)dout.p);
+    OV_CHECK(hipDeviceSynchronize());                    // (mlist is freed at the end of this scope)
+  }
+  // chunks of pairs whose histograms fit 2^30 counters (none at all when no pair has more than kMediumPair seeds)
+  uint64_t last_base = 0, last_size = 0;
+  if (NP) {
+    OV_CHECK(hipMemcpy(&last_base, (const uint64_t*)hbase.p + (NP - 1), 8, hipMemcpyDeviceToHost));
+    OV_CHECK(hipMemcpy(&last_size, (const uint64_t*)hsize.p + (NP - 1), 8, hipMemcpyDeviceToHost));
+  }
+  const bool any_hist = last_base + last_size > 0;
+  const size_t NPh = any_hist ? (size_t)NP : 0;
+  std::vector<uint64_t> h_hbase(NPh), h_soff(NPh), h_hsize(NPh);
+  if (any_hist) {
   OV_CHECK(hipMemcpy(h_hbase.data(), hbase.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
   OV_CHECK(hipMemcpy(h_soff.data(), soff.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
   OV_CHECK(hipMemcpy(h_hsize.data(), hsize.p, 8 * (size_t)NP, hipMemcpyDeviceToHost));
+  }
   const uint64_t cap = 1ull << 30;
   Buf hist;
   uint64_t hist_cap = 0;
-  for (uint64_t u0 = 0; u0 < NP;) {
+  for (uint64_t u0 = 0; any_hist && u0 < NP;) {
     uint64_t u1 = u0, tot = 0;
     while (u1 < NP && (u1 == u0 || tot + h_hsize[(size_t)u1] <= cap)) { tot += h_hsize[(size_t)u1]; u1++; }
+    if (tot == 0) { u0 = u1; continue; }                 // no pair of this chunk needs a histogram
     if (tot > hist_cap) { if (hist.p) { (void)hipFree(hist.p); hist.p = nullptr; } if (hist.alloc(4 * (size_t)tot)) return -1; hist_cap = tot; }
     OV_CHECK(hipMemsetAsync(hist.p, 0, 4 * (size_t)tot, nullptr));
     const uint64_t s0 = h_soff[(size_t)u0], s1 = u1 < NP ? h_soff[(size_t)u1] : NS;
     hipLaunchKernelGGL(k_scatter_hist, dim3((unsigned)((s1 - s0 + 255) / 256)), blk, 0, nullptr, (const int32_t*)dv.p, (int64_t)s0, (int64_t)s1,
-                       (const uint64_t*)soff.p, (int64_t)u0, (int64_t)u1, (const DPair*)dpairs.p, h_hbase[(size_t)u0], (uint32_t*)hist.p);
+                       (const uint64_t*)soff.p, (int64_t)u0, (int64_t)u1, (const DPair*)dpairs.p, h_hbase[(size_t)u0], (uint32_t*)hist.p,
+                       kMediumPair);
     hipLaunchKernelGGL(k_band_select, dim3((unsigned)(u1 - u0)), blk, 0, nullptr, (const DPair*)dpairs.p + u0, (uint32_t*)hist.p,
-                       (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, h_hbase[(size_t)u0], kSmallPair, bc,
+                       (const unsigned long long*)uc.p + u0, (const int32_t*)dfirst.p + u0, h_hbase[(size_t)u0], kMediumPair, bc,
                        (pw_overlap_band*)dout.p + u0);
     u0 = u1;
   }
