@@ -231,6 +231,9 @@ int batch_build(pw_batch* b) {
   b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
   // ---- pass 1: per-pair plans (dptable_init arithmetic) and batch statistics ----
   int64_t maxspan = 0, maxmin = 0; int maxnd = 0; int64_t sumnd = 0; int nsolv = 0;
+  // standard mode, a batch of few pairs: the strip pipeline solves the pairs one after another (each with the whole chip),
+  // the workgroup-per-pair kernels all of them at once -- estimated times of both (tests/micro/few_pairs.py)
+  double est_strips_ms = 0.0, est_wgroups_ms = 0.0;
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
   for (int32_t k = 0; k < b->n; k++) {
@@ -259,6 +262,11 @@ int batch_build(pw_batch* b) {
       maxspan = std::max<int64_t>(maxspan, (int64_t)p.origin_len + p.mutant_len + 2);
       maxmin = std::max<int64_t>(maxmin, std::min(p.origin_len, p.mutant_len));
       maxnd = std::max(maxnd, pl.ndiag); sumnd += pl.ndiag; nsolv++;
+      if (b->mode == pw::STD_MODE) {
+        const double X = p.origin_len, Y = p.mutant_len;
+        est_strips_ms += 0.04 + 0.0105 * ceil((X + 1) / 64.0) + 0.000095 * (Y + 64);
+        est_wgroups_ms = std::max(est_wgroups_ms, (X + Y) * (pl.ndiag <= 2048 ? 0.00045 : 0.0036));
+      }
     }
     b->descs[k] = d;
   }
@@ -334,10 +342,11 @@ int batch_build(pw_batch* b) {
     const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && (double)maxspan * maxabs < (double)(1 << 25) &&
                           b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
                           !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED)) && !env_int("PWLIB_NO_STRIP", 0);
-    // ... always for tables wider than a workgroup holds; and for the few-pairs case (strip pairs run one after another,
-    // each with the whole chip: 2 kb x 2 kb in 0.6 ms against 13.6 ms for one workgroup of 32-diagonal lanes, 8 kb x 8 kb
-    // 2.3 ms against 89 ms -- tests/micro/mid_pairs.py), when the table spans at least two strips
-    const bool few = latency_mode && ((nsolv <= 4 && d.X >= 127) || (nsolv <= 16 && d.ndiag >= 4096));
+    // ... always for tables wider than a workgroup holds; and for batches of a few pairs (at most 256: latency mode) when the
+    // strips of all pairs, one pair after another, are estimated to finish before the slowest workgroup would (2 kb x 2 kb:
+    // 0.6 ms per pair against 13.6 ms for one workgroup of 32-diagonal lanes -- up to 16 such pairs; 1 kb x 1 kb: 0.3 ms
+    // against 1.0 ms -- up to 2), for tables that span at least two strips
+    const bool few = latency_mode && d.X >= 127 && est_strips_ms < 0.9 * est_wgroups_ms;
     if (strip_ok && ((b->flags & PW_FLAG_FORCE_STRIP) || d.ndiag > 2048 * pw::kMaxWavesPerPair || (few && !env_int("PWLIB_NO_SMALL_STRIP", 0)))) {
       // one pair wider than a workgroup, integer scores, simple scoring: rows in strips of 64, a pipeline of wavefronts
       const int nstrips = (d.X + 1 + 63) / 64, nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
