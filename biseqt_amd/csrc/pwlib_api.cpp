@@ -234,6 +234,8 @@ int batch_build(pw_batch* b) {
   // standard mode, a batch of few pairs: the strip pipeline solves the pairs one after another (each with the whole chip),
   // the workgroup-per-pair kernels all of them at once -- estimated times of both (tests/micro/few_pairs.py)
   double est_strips_ms = 0.0, est_wgroups_ms = 0.0;
+  // one step of a workgroup's pair: 8 wavefronts with 4 / 8 / 16 / 32 diagonals per lane (tests/micro/few_pairs.py)
+  auto wg_us_per_step = [](int ndiag) { return ndiag <= 2048 ? 0.45 : (ndiag <= 4096 ? 0.7 : (ndiag <= 8192 ? 1.3 : 5.5)); };
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
   for (int32_t k = 0; k < b->n; k++) {
@@ -265,7 +267,7 @@ int batch_build(pw_batch* b) {
       if (b->mode == pw::STD_MODE) {
         const double X = p.origin_len, Y = p.mutant_len;
         est_strips_ms += 0.04 + 0.0105 * ceil((X + 1) / 64.0) + 0.000095 * (Y + 64);
-        est_wgroups_ms = std::max(est_wgroups_ms, (X + Y) * (pl.ndiag <= 2048 ? 0.00045 : 0.0036));
+        est_wgroups_ms = std::max(est_wgroups_ms, (X + Y) * wg_us_per_step(pl.ndiag) * 1e-3);
       }
     }
     b->descs[k] = d;
@@ -369,9 +371,16 @@ int batch_build(pw_batch* b) {
       bk = pw::plan_pick_bk(d.ndiag, pw::kSupportedBK, pw::kNumSupportedBK);
       nl = 64;
       if (bk == 0) {
-        // wider than one wavefront holds: a workgroup of nw wavefronts, 2048 diagonals each
+        // wider than one wavefront holds: a workgroup of nw wavefronts, 2048 diagonals each -- in latency mode as many
+        // wavefronts as a workgroup takes, with as few diagonals per lane as that allows (2 kb x 2 kb: 8 x 8 instead of
+        // 2 x 32 diagonals per lane)
         bk = 32;
-        nw = (d.ndiag + 2047) / 2048;
+        if (latency_mode) {
+          for (int cand : {8, 16, 32}) {
+            if ((int64_t)64 * pw::kMaxWavesPerPair * cand >= d.ndiag) { bk = cand; break; }
+          }
+        }
+        nw = (d.ndiag + 64 * bk - 1) / (64 * bk);
         nl = 64 * nw;
       } else if (latency_mode && bk >= 16) {
         // a handful of pairs cannot fill the chip anyway: spread each over up to 8 wavefronts with few diagonals
