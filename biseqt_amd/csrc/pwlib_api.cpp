@@ -375,7 +375,9 @@ int batch_build(pw_batch* b) {
         // wavefronts as a workgroup takes, with as few diagonals per lane as that allows (2 kb x 2 kb: 8 x 8 instead of
         // 2 x 32 diagonals per lane)
         bk = 32;
-        if (latency_mode) {
+        if (latency_mode || !env_int("PWLIB_MW_WIDE_LANES", 0)) {
+          // (also with many pairs: at 32 diagonals per lane the kernel spills 1.4 - 3 KB of registers per lane; 300 pairs of
+          //  10 kb with a 3001-diagonal band: 208 ms with 2 x 32, measured below with 6 x 8)
           for (int cand : {8, 16, 32}) {
             if ((int64_t)64 * pw::kMaxWavesPerPair * cand >= d.ndiag) { bk = cand; break; }
           }
