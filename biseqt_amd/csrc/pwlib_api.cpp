@@ -328,7 +328,13 @@ int batch_build(pw_batch* b) {
       if (64 / nl >= 2 && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
     }
     const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
-    if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }
+    if (latency_mode && bk1 && !forced) {
+      // a few hundred pairs at most: the time is one wavefront's chain of steps, so as few diagonals per lane as the band
+      // allows -- several pairs side by side where they fit, which changes the number of wavefronts, not the chain
+      // (2 kb pairs, band radius 20: 1.41 -> 0.49 ms; radius 50: 0.87 -> 0.49 ms)
+      pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 64 / pnl >= 2 ? 1 : 0;
+    }
+    else if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }
     else if (bk1) { pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 0; }
     // one pair per wavefront with 16+ diagonals per lane is a long serial chain: small batches go multi-wavefront
     if (latency_mode && pbk >= 16 && !pseg) pbk = 0;
@@ -413,8 +419,8 @@ int batch_build(pw_batch* b) {
     // consecutive (similar length) pairs share a wavefront
     const int ppw = pseg ? 64 / pnl : 1;
     b->packed_seg = pseg; b->packed_rule = prule;
-    // rule 0, one pair per wavefront, scores below 2048: the kernel that holds every score times 4 (WaveFill16, RULE 3)
-    if (prule == 0 && !pseg && (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 2047 && !env_int("PWLIB_NO_SCALED16", 0))
+    // rule 0, scores below 2048: the kernel that holds every score times 4 (WaveFill16, RULE 3)
+    if (prule == 0 && (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 2047 && !env_int("PWLIB_NO_SCALED16", 0))
       b->packed_rule = 3;
     BkClass& c = b->classes[0];
     for (size_t i = 0; i < c.order.size(); i += ppw) {

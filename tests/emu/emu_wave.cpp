@@ -166,7 +166,9 @@ template <int BK> struct Run16<int32_t, BK> {
       const int rule = a.endrule == pw::END_BANDED_OVERLAP ? 1 : (a.endrule == pw::END_CORNER ? 2 : 0);
       if (rule == 0) {
         // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048)
-        if (g_packed_mode == 3) emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 3> w(a, wd); w.run(); });
+        // packed16 == 4: the same, lane-packed form
+        if (g_packed_mode == 4) { wd.nl = pd.nl; emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 3> w(a, wd); w.run(); }); }
+        else if (g_packed_mode == 3) emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 3> w(a, wd); w.run(); });
         else if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 0> w(a, wd); w.run(); });
         else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 0> w(a, wd); w.run(); });
       } else if (rule == 1) {

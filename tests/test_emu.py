@@ -119,9 +119,10 @@ def test_emu_packed16_local(oracle):
             assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
         if min(X, len(m)) * max(kw['match'], kw['mismatch'], 0) <= 2047:
             # 3: every score held times 4 (tie nibble by one three-operand add; admitted below 2048)
-            c = emu.solve(o, m, bk=bk, packed16=3, **kw)
-            for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
-                assert a.get(key) == c.get(key), (trial, 'scaled', key, a.get(key), c.get(key), kw, bk)
+            for pk in (3, 4):                                         # 4: the lane-packed form of it
+                c = emu.solve(o, m, bk=bk, packed16=pk, **kw)
+                for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+                    assert a.get(key) == c.get(key), (trial, 'scaled', pk, key, a.get(key), c.get(key), kw, bk)
         n += 1
     assert n > 50
 
