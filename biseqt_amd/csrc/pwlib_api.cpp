@@ -325,11 +325,14 @@ int batch_build(pw_batch* b) {
       const double u1 = meannd / (64.0 * bk);
       if (u1 > util1 + 1e-9) { util1 = u1; bk1 = bk; }                       // smallest BK that fits
       const double up = (double)(64 / nl) * meannd / (64.0 * bk);
-      if (64 / nl >= 2 && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
+      // (packing must leave at least one wavefront per SIMD: 20 000 pairs with a 21-diagonal band packed 64 to a wavefront are
+      //  313 wavefronts with 12 cells per lane and step -- 0.69 ms against 0.41 ms for 10 to a wavefront)
+      const bool enough = forced || (int64_t)(nsolv + 64 / nl - 1) / (64 / nl) >= 1024;
+      if (64 / nl >= 2 && enough && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
     }
     const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
-    if (latency_mode && bk1 && !forced) {
-      // a few hundred pairs at most: the time is one wavefront's chain of steps, so as few diagonals per lane as the band
+    if ((latency_mode || nsolv < 1024) && bk1 && !forced) {
+      // fewer pairs than SIMDs: the time is one wavefront's chain of steps, so as few diagonals per lane as the band
       // allows -- several pairs side by side where they fit, which changes the number of wavefronts, not the chain
       // (2 kb pairs, band radius 20: 1.41 -> 0.49 ms; radius 50: 0.87 -> 0.49 ms)
       pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 64 / pnl >= 2 ? 1 : 0;
