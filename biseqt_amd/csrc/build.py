@@ -45,7 +45,7 @@ def _jobs():
         obj = os.path.join(OBJ_DIR, 'pw_fill_tile_%s.o' % tn)
         cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_tile_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tile_tu.hip')]))
-    for bk, rule in [(bk, 0) for bk in PACKED_BKS] + [(bk, r) for r in (1, 2) for bk in PACKED_BKS if bk <= 20] + [(bk, 3) for bk in PACKED_BKS]:
+    for bk, rule in [(bk, 0) for bk in PACKED_BKS] + [(bk, r) for r in (1, 2) for bk in PACKED_BKS] + [(bk, 3) for bk in PACKED_BKS]:
         obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d_r%d.o' % (bk, rule))
         # max-ilp scheduling: dependent VOP3P ops need a wait state between them; the default (occupancy first)
         # schedule leaves ~15% of the issue slots of the packed kernel to s_nop, this one none (measured)

@@ -117,8 +117,8 @@ PW_DECL(f64, double)
 #undef PW_DECL
 #define PW_DECL16(BK, R) hipError_t launch_fill16_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t);
 PW_DECL16(4, 0) PW_DECL16(8, 0) PW_DECL16(12, 0) PW_DECL16(16, 0) PW_DECL16(20, 0) PW_DECL16(24, 0) PW_DECL16(28, 0) PW_DECL16(32, 0)
-PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1)
-PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2)
+PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1) PW_DECL16(24, 1) PW_DECL16(28, 1) PW_DECL16(32, 1)
+PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2) PW_DECL16(24, 2) PW_DECL16(28, 2) PW_DECL16(32, 2)
 PW_DECL16(4, 3) PW_DECL16(8, 3) PW_DECL16(12, 3) PW_DECL16(16, 3) PW_DECL16(20, 3) PW_DECL16(24, 3) PW_DECL16(28, 3) PW_DECL16(32, 3)
 #undef PW_DECL16
 
@@ -144,8 +144,8 @@ hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule
 #define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16_bk##BK##_r##R(a, seg, nwaves, st);
   switch (bk * 4 + rule) {
     PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
-    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1)
-    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2)
+    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1) PW_CASE16(24, 1) PW_CASE16(28, 1) PW_CASE16(32, 1)
+    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2) PW_CASE16(24, 2) PW_CASE16(28, 2) PW_CASE16(32, 2)
     PW_CASE16(4, 3) PW_CASE16(8, 3) PW_CASE16(12, 3) PW_CASE16(16, 3) PW_CASE16(20, 3) PW_CASE16(24, 3) PW_CASE16(28, 3) PW_CASE16(32, 3)
     default: return hipErrorInvalidValue;
   }

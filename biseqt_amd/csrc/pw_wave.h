@@ -982,7 +982,9 @@ struct WaveFill16 {
           // `s` is the captured value of the diagonal's last cell (_banded_find_optimal, _pw_internals.c:364-414)
           const bool ends_right = d < X - Y;
           x = ends_right ? d + Y : X; y = ends_right ? Y : X - d;
-          k = (uint64_t)(uint32_t)dd;
+          // ties: banded overlap takes the diagonals in ascending order, standard overlap the last column top-down and then
+          // the last row left to right (_std_find_optimal: on the full band every diagonal ends on one of the two)
+          k = endrule == END_STD_OVERLAP ? (uint64_t)(uint32_t)(x < X ? x : X + y) : (uint64_t)(uint32_t)dd;
           if (RL == 2) ok = d == X - Y;
         } else if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
         else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;

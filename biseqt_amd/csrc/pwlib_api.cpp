@@ -294,8 +294,11 @@ int batch_build(pw_batch* b) {
   // from the table edge (min(X,Y) substitutions) -- for B_GLOBAL after the gap run from (0, 0) to that diagonal.
   int pbk = 0, pnl = 0, pseg = 0, prule = -1;
   if (b->variant == pw::VAR_FAST_ANY_TRACK && track) prule = 0;
-  else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_EDGE && b->endrule == pw::END_BANDED_OVERLAP) prule = 1;
-  else if (b->mode == pw::BANDED_MODE && b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
+  // (B_OVERLAP, and standard-mode OVERLAP: the same begin rule, the best last cell of a diagonal, another order of ties)
+  else if (b->variant == pw::VAR_FAST && b->brule == pw::BRULE_EDGE &&
+           (b->endrule == pw::END_BANDED_OVERLAP || b->endrule == pw::END_STD_OVERLAP)) prule = 1;
+  // (B_GLOBAL, and standard-mode GLOBAL: the same begin / end rule on the band [-Y, X])
+  else if (b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
   bool pfits = false;
   // (any substitution may be the best one: the API accepts mismatch > match)
   if (prule == 0) pfits = (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 8000;
@@ -304,7 +307,7 @@ int batch_build(pw_batch* b) {
     const double worst = std::max(0.0, -std::min(mt, mm));
     const double lowest = (double)maxmin * worst + fabs(b->go) + fabs(b->ge) * (maxnd + 2);
     const double highest = (double)maxmin * std::max(0.0, std::max(mt, mm));
-    pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && maxnd <= 64 * 20 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
+    pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
   }
   if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd <= 2048 &&
@@ -318,7 +321,6 @@ int batch_build(pw_batch* b) {
     double util1 = -1, utilp = -1; int bk1 = 0, bkp = 0, nlp = 0;
     for (int i = 0; i < pw::kNumPackedBK; i++) {
       const int bk = pw::kPackedBK[i];
-      if (prule > 0 && bk > 20) continue;                  // rules 1 / 2 are built for BK <= 20
       if (forced && atoi(forced) != bk) continue;
       const int nl = (maxnd + bk - 1) / bk;
       if (nl > 64) continue;

@@ -43,7 +43,7 @@ for count in (1, 16, 300):
         for r in (50, 200, 600, 1500, 4000):
             if r * 2 > n:
                 continue
-            for name, t in (('B_LOCAL', 1), ('B_OVERLAP', 0), ('B_GLOBAL', 2)):
+            for name, t in (('B_LOCAL', 1), ('B_GLOBAL', 0), ('B_OVERLAP', 2)):
                 run('%3d x %5d banded r=%4d %s' % (count, n, r, name), P, alnmode=1, alntype=t, diag_range=(-r, r), **base)
         if n <= 10000 and count <= 16:
             run('%3d x %5d standard LOCAL' % (count, n), P, alnmode=0, alntype=1, **base)

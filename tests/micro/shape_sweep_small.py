@@ -18,10 +18,10 @@ for n in (100, 300, 1000):
         o = synth.rand_seqs(rng, count, n)
         P = [(a, synth.mutate(rng, a, 0.05, 0.02, 0.4)) for a in o]
         shapes = [('standard LOCAL', dict(alnmode=0, alntype=1)), ('standard GLOBAL', dict(alnmode=0, alntype=0)),
-                  ('standard OVERLAP', dict(alnmode=0, alntype=3))]
+                  ('standard OVERLAP', dict(alnmode=0, alntype=4))]
         for r in (10, 40):
             shapes.append(('banded r=%d B_LOCAL' % r, dict(alnmode=1, alntype=1, diag_range=(-r, r))))
-            shapes.append(('banded r=%d B_OVERLAP' % r, dict(alnmode=1, alntype=0, diag_range=(-r, r))))
+            shapes.append(('banded r=%d B_OVERLAP' % r, dict(alnmode=1, alntype=2, diag_range=(-r, r))))
         for name, kw in shapes:
             kw = dict(kw); kw.update(base)
             with BatchAligner(P, flags=W.PW_FLAG_PROFILE, **kw) as b:

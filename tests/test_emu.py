@@ -167,6 +167,37 @@ def test_emu_packed16_overlap_and_global(oracle):
     assert n > 90
 
 
+def test_emu_packed16_standard_mode_global_and_overlap(oracle):
+    """Standard-mode GLOBAL and OVERLAP are the global / overlap rules on the band [-Y, X] (OVERLAP with its own order of
+    ties among the last cells): the packed rule-2 / rule-1 bodies must equal the oracle there too (empty and one-letter
+    sequences, unrelated sequences whose scores go far below zero, both lane layouts)."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(23)
+    n = 0
+    for trial in range(120):
+        L = int(rng.choice([2, 4]))
+        X = int(rng.integers(0, 150)) if trial % 5 else int(rng.integers(0, 4))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        if trial % 3 == 0:
+            m = rng.integers(0, L, int(rng.integers(0, 150))).astype(np.uint8)
+        else:
+            m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 5))).astype(np.uint8)
+        kw = dict(L=L, mode=0, alntype=0 if trial % 2 else 4, match=float(rng.choice([1, 2, 5])),      # GLOBAL / OVERLAP
+                  mismatch=float(rng.choice([0, -1, -3])), go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
+        if kw['alntype'] == 4 and trial % 3 == 1 and X > 10:      # suffix of o = prefix of m: several last cells may tie
+            m = np.concatenate([o[int(rng.integers(0, X)):], rng.integers(0, L, int(rng.integers(0, 40))).astype(np.uint8)])
+        nd = X + len(m) + 1
+        bk = next((b for b in (4, 8, 16, 20) if 64 * b >= nd), None)
+        if bk is None:
+            continue
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=bk, packed16=1 + trial % 2, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
+        n += 1
+    assert n > 100
+
+
 def test_emu_packed16_overlap_last_cell_on_a_block_boundary(oracle):
     """Regression (GPU fuzz, seed 51): a diagonal whose LAST cell is the last step of a block that the planner's steady
     range still covers -- the overlap / global rules must run the edge body there to capture it."""

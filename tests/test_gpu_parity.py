@@ -430,6 +430,46 @@ def test_scaled_packed_kernel_at_its_admission_bound(oracle):
             assert runs[0][1]['score'][0] == n * match
 
 
+def test_standard_mode_global_and_overlap_on_the_packed_kernels(oracle):
+    """Standard-mode GLOBAL and OVERLAP batches take the packed rule-2 / rule-1 kernels -- the global / overlap rules on the
+    band [-Y, X], OVERLAP with its own order of ties among the last cells -- and must equal the 32-bit kernel for every pair
+    and the oracle on a sample; unrelated pairs drive the scores far below zero, suffix-prefix pairs make last cells tie,
+    empty and one-letter sequences sit in the same batch."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(99)
+    pairs = []
+    for k in range(1200):
+        n = int(rng.integers(0, 600)) if k % 7 else int(rng.integers(0, 3))
+        o = synth.rand_seqs(rng, 1, n)[0]
+        if k % 3 == 0:
+            m = synth.rand_seqs(rng, 1, int(rng.integers(0, 600)))[0]
+        elif k % 3 == 1 and n > 20:                        # a suffix of o is a prefix of m
+            m = np.concatenate([o[int(rng.integers(0, n)):], synth.rand_seqs(rng, 1, int(rng.integers(0, 80)))[0]])
+        else:
+            m = synth.mutate(rng, o, 0.06, 0.03, 0.4)
+        pairs.append((o, m))
+    for alntype, tag in ((0, ', 2>'), (4, ', 1>')):         # GLOBAL -> rule 2, OVERLAP -> rule 1
+        kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, match_score=2, mismatch_score=-3, go_score=-4, ge_score=-1)
+        runs = []
+        for flags in (0, W.PW_FLAG_NO_PACKED16):
+            with BatchAligner(pairs, flags=flags, **kw) as b:
+                name = b.kernel_name
+                res = b.run()
+                runs.append((name, res.copy(), b.transcripts(res)))
+        assert 'k_fill16' in runs[0][0] and tag in runs[0][0], runs[0][0]
+        assert 'k_fill16' not in runs[1][0]
+        assert (runs[0][1] == runs[1][1]).all() and runs[0][2] == runs[1][2], alntype
+        for k in range(0, 1200, 23):
+            r = oracle.solve(pairs[k][0], pairs[k][1], L=4, mode=0, alntype=alntype, match=2, mismatch=-3, go=-4, ge=-1)
+            assert (runs[0][1]['opt_i'][k], runs[0][1]['opt_j'][k]) == r['opt'] and runs[0][1]['score'][k] == r['score'], (alntype, k)
+            if r['would_panick']:                          # (the reference exits here, pw.c:132-134: reported as a status)
+                assert runs[0][1]['status'][k] & W.PW_ST_PANICK, (alntype, k)
+            else:
+                assert (runs[0][2][k] or '') == (r['transcript'] or ''), (alntype, k)
+
+
 def test_traceback_from_explicit_end_cells(oracle):
     """dptable_traceback accepts any end cell (pw.c:116-123), not only the optimum."""
     from biseqt_amd.batch import BatchAligner
