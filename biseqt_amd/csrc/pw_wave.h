@@ -880,7 +880,7 @@ struct WaveFill16 {
   PW_FN int tbegin_of(int j) const {      // RULE != 0: the step of the diagonal's cell that may begin an alignment
     const int dd = li * BK + j, d = pd.dmin + dd;
     if (!valid || dd >= ndiag) return 32767;
-    if (RL == 2 && d != 0) return 32767;                 // B_GLOBAL: cell (0, 0) only
+    if ((RL == 2 || a.brule == BRULE_ORIGIN) && d != 0) return 32767;   // begin at cell (0, 0) only (B_GLOBAL, GLOBAL, START_ANCHORED_OVERLAP)
     return (d < 0 ? -d : d) - pd.s0;                       // the first cell of the diagonal lies on the table edge
   }
   PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)X ? (uint32_t)oseq[i] : SENT_O; }
@@ -985,7 +985,7 @@ struct WaveFill16 {
           // ties: banded overlap takes the diagonals in ascending order, standard overlap the last column top-down and then
           // the last row left to right (_std_find_optimal: on the full band every diagonal ends on one of the two)
           k = endrule == END_STD_OVERLAP ? (uint64_t)(uint32_t)(x < X ? x : X + y) : (uint64_t)(uint32_t)dd;
-          if (RL == 2) ok = d == X - Y;
+          if (RL == 2 || endrule == END_CORNER) ok = d == X - Y;      // end at cell (X, Y) only
         } else if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
         else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
         const bool better = ok && valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));

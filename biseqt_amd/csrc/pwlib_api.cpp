@@ -297,6 +297,10 @@ int batch_build(pw_batch* b) {
   // (B_OVERLAP, and standard-mode OVERLAP: the same begin rule, the best last cell of a diagonal, another order of ties)
   else if (b->variant == pw::VAR_FAST && b->brule == pw::BRULE_EDGE &&
            (b->endrule == pw::END_BANDED_OVERLAP || b->endrule == pw::END_STD_OVERLAP)) prule = 1;
+  // (the two mixed standard-mode types, begin and end rule read at run time by the rule-1 body: START_ANCHORED_OVERLAP begins
+  //  at (0, 0) and ends like OVERLAP, END_ANCHORED_OVERLAP begins like OVERLAP and ends at (X, Y))
+  else if (b->variant == pw::VAR_FAST && ((b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_STD_OVERLAP) ||
+                                         (b->brule == pw::BRULE_EDGE && b->endrule == pw::END_CORNER))) prule = 1;
   // (B_GLOBAL, and standard-mode GLOBAL: the same begin / end rule on the band [-Y, X])
   else if (b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
   bool pfits = false;

@@ -163,7 +163,8 @@ template <int BK> struct Run16<int32_t, BK> {
       const bool seg = g_packed_mode == 1;
       wd.nl = seg ? pd.nl : 64;
       Emu emu;
-      const int rule = (a.endrule == pw::END_BANDED_OVERLAP || a.endrule == pw::END_STD_OVERLAP) ? 1 : (a.endrule == pw::END_CORNER ? 2 : 0);
+      const int rule = (a.endrule == pw::END_BANDED_OVERLAP || a.endrule == pw::END_STD_OVERLAP) ? 1
+                       : (a.endrule == pw::END_CORNER ? (a.brule == pw::BRULE_ORIGIN ? 2 : 1) : 0);
       if (rule == 0) {
         // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048)
         // packed16 == 4: the same, lane-packed form
@@ -241,7 +242,9 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
   const bool rule_local = bany && track;
-  const bool rule_overlap = pl.brule == pw::BRULE_EDGE && (pl.endrule == pw::END_BANDED_OVERLAP || pl.endrule == pw::END_STD_OVERLAP);
+  const bool rule_overlap = (pl.brule == pw::BRULE_EDGE && (pl.endrule == pw::END_BANDED_OVERLAP || pl.endrule == pw::END_STD_OVERLAP)) ||
+                            (pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_STD_OVERLAP) ||
+                            (pl.brule == pw::BRULE_EDGE && pl.endrule == pw::END_CORNER);
   const bool rule_global = pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_CORNER;      // B_GLOBAL, and GLOBAL on the full band
   const int use16 = packed16 && !generic && (rule_local || rule_overlap || rule_global) && bk % 4 == 0 && sizeof(T) == 4;
   g_packed_mode = packed16;

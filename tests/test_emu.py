@@ -182,9 +182,9 @@ def test_emu_packed16_standard_mode_global_and_overlap(oracle):
             m = rng.integers(0, L, int(rng.integers(0, 150))).astype(np.uint8)
         else:
             m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 5))).astype(np.uint8)
-        kw = dict(L=L, mode=0, alntype=0 if trial % 2 else 4, match=float(rng.choice([1, 2, 5])),      # GLOBAL / OVERLAP
+        kw = dict(L=L, mode=0, alntype=(0, 4, 5, 6)[trial % 4], match=float(rng.choice([1, 2, 5])),    # GLOBAL / OVERLAP / START_- / END_ANCHORED_OVERLAP
                   mismatch=float(rng.choice([0, -1, -3])), go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
-        if kw['alntype'] == 4 and trial % 3 == 1 and X > 10:      # suffix of o = prefix of m: several last cells may tie
+        if kw['alntype'] >= 4 and trial % 3 == 1 and X > 10:      # suffix of o = prefix of m: several last cells may tie
             m = np.concatenate([o[int(rng.integers(0, X)):], rng.integers(0, L, int(rng.integers(0, 40))).astype(np.uint8)])
         nd = X + len(m) + 1
         bk = next((b for b in (4, 8, 16, 20) if 64 * b >= nd), None)

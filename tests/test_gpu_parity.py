@@ -450,7 +450,7 @@ def test_standard_mode_global_and_overlap_on_the_packed_kernels(oracle):
         else:
             m = synth.mutate(rng, o, 0.06, 0.03, 0.4)
         pairs.append((o, m))
-    for alntype, tag in ((0, ', 2>'), (4, ', 1>')):         # GLOBAL -> rule 2, OVERLAP -> rule 1
+    for alntype, tag in ((0, ', 2>'), (4, ', 1>'), (5, ', 1>'), (6, ', 1>')):   # GLOBAL -> rule 2; OVERLAP, START_- and END_ANCHORED_OVERLAP -> rule 1
         kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, match_score=2, mismatch_score=-3, go_score=-4, ge_score=-1)
         runs = []
         for flags in (0, W.PW_FLAG_NO_PACKED16):
