@@ -236,6 +236,10 @@ int batch_build(pw_batch* b) {
   double est_strips_ms = 0.0, est_wgroups_ms = 0.0;
   // one step of a workgroup's pair: 8 wavefronts with 4 / 8 / 16 / 32 diagonals per lane (tests/micro/few_pairs.py)
   auto wg_us_per_step = [](int ndiag) { return ndiag <= 2048 ? 0.45 : (ndiag <= 4096 ? 0.7 : (ndiag <= 8192 ? 1.3 : 5.5)); };
+  // ... the same for f64 scores (the wide lanes spill kilobytes of registers: 8 kb x 8 kb takes 317 ms), and the time-blocked
+  // tiled kernel, which like the strips takes the pairs one after another (0.43 us per anti-diagonal, whatever the width)
+  auto wg_us_per_step_f64 = [](int ndiag) { return ndiag <= 1024 ? 0.47 : (ndiag <= 2048 ? 0.6 : (ndiag <= 4096 ? 1.0 : (ndiag <= 8192 ? 2.7 : 19.8))); };
+  double est_tiles_ms = 0.0, est_wgroups_int_ms = 0.0, est_wgroups_f64_ms = 0.0;
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
   for (int32_t k = 0; k < b->n; k++) {
@@ -264,6 +268,12 @@ int batch_build(pw_batch* b) {
       maxspan = std::max<int64_t>(maxspan, (int64_t)p.origin_len + p.mutant_len + 2);
       maxmin = std::max<int64_t>(maxmin, std::min(p.origin_len, p.mutant_len));
       maxnd = std::max(maxnd, pl.ndiag); sumnd += pl.ndiag; nsolv++;
+      {
+        const double steps = (double)pl.nblocks * 16.0;        // anti-diagonals of the (banded) table
+        est_tiles_ms += 0.05 + steps * 0.00043;
+        est_wgroups_int_ms = std::max(est_wgroups_int_ms, steps * wg_us_per_step(pl.ndiag) * 1e-3);
+        est_wgroups_f64_ms = std::max(est_wgroups_f64_ms, steps * wg_us_per_step_f64(pl.ndiag) * 1e-3);
+      }
       if (b->mode == pw::STD_MODE) {
         const double X = p.origin_len, Y = p.mutant_len;
         est_strips_ms += 0.04 + 0.0105 * ceil((X + 1) / 64.0) + 0.000095 * (Y + 64);
@@ -375,8 +385,12 @@ int batch_build(pw_batch* b) {
       b->fifo_bytes = std::max<size_t>(b->fifo_bytes, (size_t)nstrips * (size_t)((d.Y + 1 + 63) / 64 * 64) * 8);
       continue;
     }
+    // a few pairs with bands wider than a wavefront holds, not served by the strips (f64 scores, a substitution matrix,
+    // go > 0, banded): the tiled kernel when all pairs, one after another, are estimated to finish before the slowest workgroup
+    const bool few_tiled = latency_mode && d.ndiag > 1024 && !(b->flags & PW_FLAG_DUMP_SCORES) && !env_int("PWLIB_NO_SMALL_TILED", 0) &&
+                           est_tiles_ms < 0.9 * (b->use_f64 ? est_wgroups_f64_ms : est_wgroups_int_ms);
     if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
-    else if ((b->flags & PW_FLAG_FORCE_TILED) || d.ndiag > 2048 * pw::kMaxWavesPerPair) {
+    else if ((b->flags & PW_FLAG_FORCE_TILED) || d.ndiag > 2048 * pw::kMaxWavesPerPair || few_tiled) {
       // wider than a workgroup holds (or forced): time-blocked tiles of the band, one pair after another
       if (b->flags & PW_FLAG_DUMP_SCORES) return fail("the score plane is not available for tiled (very wide) tables");
       bk = pw::kTileBKHost;
@@ -399,7 +413,9 @@ int batch_build(pw_batch* b) {
         }
         nw = (d.ndiag + 64 * bk - 1) / (64 * bk);
         nl = 64 * nw;
-      } else if (latency_mode && bk >= 16) {
+      } else if ((latency_mode && bk >= 16) || (b->use_f64 && bk >= 32)) {
+        // (f64 with 32 diagonals per lane needs more registers than a wavefront has: 3000 pairs with a 1201-diagonal band
+        //  take 166 ms on one wavefront each, 47 ms on five wavefronts of 4 diagonals per lane)
         // a handful of pairs cannot fill the chip anyway: spread each over up to 8 wavefronts with few diagonals
         // per lane (the step count is fixed by X + Y; the work per step shrinks 4-8x, the exchange costs ~0.3 us)
         for (int cand : {4, 8, 16}) {
