@@ -450,8 +450,7 @@ def main():
         line.update(extras)
         if variants:
             line['variants'] = variants
-        if cpu is not None:
-            line['cpu_baseline'] = cpu
+        line['cpu_baseline'] = cpu          # timed at N = 1 only (null otherwise, or with --no-cpu-baseline)
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + '\n').encode())
     for b in batches:
