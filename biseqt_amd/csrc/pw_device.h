@@ -158,6 +158,16 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int
   w.run();
 }
 
+// The same 16-bit body on a workgroup of up to 8 wavefronts per pair (K2a's exchange through LDS): bands of 2049 .. 16 384
+// diagonals, e.g. standard-mode tables of 1 .. 8 kb, whose scores fit the packed kernel.  One WaveDesc per pair,
+// nl = 64 x wavefronts.
+template <int BK, int RULE>
+__global__ __launch_bounds__(512) void k_fill16_mw(const FillParams<int32_t> a) {
+  const WaveDesc wd = a.waves[blockIdx.x];
+  WaveFill16<DevPM, BK, false, RULE> w(a, wd);
+  w.run();
+}
+
 // Platform policy of a TILE of the time-blocked single-pair kernel (K2b): a workgroup of kTileLanes lanes whose
 // lane indices are global (tile * kTileCentral - kTileGhost + thread); the first kTileGhost and the last
 // kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.

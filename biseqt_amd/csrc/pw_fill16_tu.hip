@@ -15,4 +15,9 @@ hipError_t PW_CAT(PW_CAT(launch_fill16_bk, PW_BK), PW_CAT(_r, PW_RULE))(const Fi
   else hipLaunchKernelGGL((k_fill16<PW_BK, false, PW_RULE>), dim3((unsigned)nwaves), dim3(64), 0, st, a);
   return hipGetLastError();
 }
+// ... on `nw` wavefronts per pair (one workgroup each)
+hipError_t PW_CAT(PW_CAT(launch_fill16mw_bk, PW_BK), PW_CAT(_r, PW_RULE))(const FillParams<int32_t>& a, int nw, int npairs, hipStream_t st) {
+  hipLaunchKernelGGL((k_fill16_mw<PW_BK, PW_RULE>), dim3((unsigned)npairs), dim3((unsigned)(64 * nw)), 0, st, a);
+  return hipGetLastError();
+}
 }  // namespace pw

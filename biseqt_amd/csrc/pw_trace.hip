@@ -115,7 +115,8 @@ hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
 PW_DECL(i32, int32_t)
 PW_DECL(f64, double)
 #undef PW_DECL
-#define PW_DECL16(BK, R) hipError_t launch_fill16_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t);
+#define PW_DECL16(BK, R) hipError_t launch_fill16_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t); \
+  hipError_t launch_fill16mw_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t);
 PW_DECL16(4, 0) PW_DECL16(8, 0) PW_DECL16(12, 0) PW_DECL16(16, 0) PW_DECL16(20, 0) PW_DECL16(24, 0) PW_DECL16(28, 0) PW_DECL16(32, 0)
 PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1) PW_DECL16(24, 1) PW_DECL16(28, 1) PW_DECL16(32, 1)
 PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2) PW_DECL16(24, 2) PW_DECL16(28, 2) PW_DECL16(32, 2)
@@ -142,6 +143,18 @@ hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int bk, int 
 
 hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int nwaves, hipStream_t st) {
 #define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16_bk##BK##_r##R(a, seg, nwaves, st);
+  switch (bk * 4 + rule) {
+    PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
+    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1) PW_CASE16(24, 1) PW_CASE16(28, 1) PW_CASE16(32, 1)
+    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2) PW_CASE16(24, 2) PW_CASE16(28, 2) PW_CASE16(32, 2)
+    PW_CASE16(4, 3) PW_CASE16(8, 3) PW_CASE16(12, 3) PW_CASE16(16, 3) PW_CASE16(20, 3) PW_CASE16(24, 3) PW_CASE16(28, 3) PW_CASE16(32, 3)
+    default: return hipErrorInvalidValue;
+  }
+#undef PW_CASE16
+}
+
+hipError_t launch_fill16_mw(const FillParams<int32_t>& a, int bk, int rule, int nw, int npairs, hipStream_t st) {
+#define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16mw_bk##BK##_r##R(a, nw, npairs, st);
   switch (bk * 4 + rule) {
     PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
     PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1) PW_CASE16(24, 1) PW_CASE16(28, 1) PW_CASE16(32, 1)

@@ -1005,6 +1005,18 @@ struct WaveFill16 {
         const bool take = oh && (!hv || os > rs || (os == rs && ok_ < rk));
         if (take) { rs = os; rk = ok_; rx = ox; ry = oy; hv = 1; }
       }
+      // several wavefronts per pair (K2a with this body; one pair, SEG = false): the per-wave winners the same way
+      if (P::nwaves() > 1) {
+        int32_t bs = rs; uint64_t bk_ = rk; int bx = rx, by = ry, bh = 0;
+        for (int wv = 0; wv < P::nwaves(); wv++) {
+          const int32_t os = P::wave_bcast(rs, wv);
+          const uint64_t ok_ = xwave_bcast<P>(rk, wv);
+          const int ox = P::wave_bcast(rx, wv), oy = P::wave_bcast(ry, wv), oh = P::wave_bcast(hv, wv);
+          const bool take = oh && (!bh || os > bs || (os == bs && ok_ < bk_));
+          if (take) { bs = os; bk_ = ok_; bx = ox; by = oy; bh = 1; }
+        }
+        rs = bs; rk = bk_; rx = bx; ry = by; hv = bh;
+      }
       if (seg == sidx && li == 0) {
         Result r;
         r.score = (double)rs;

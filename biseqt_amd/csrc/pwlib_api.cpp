@@ -163,7 +163,7 @@ struct pw_batch {
   std::vector<int32_t> tiled;           // pairs that go through the time-blocked tiled kernel (K2b)
   void* d_state[2] = {nullptr, nullptr}; // their per-diagonal state, double buffered (shared: pairs run one after another)
   int32_t st_pitch = 0;
-  int packed_seg = 0, packed_rule = 0;
+  int packed_seg = 0, packed_rule = 0, packed_nw = 1;     // packed_nw: wavefronts per pair (K2a with the 16-bit body)
   pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
   // device
@@ -324,6 +324,21 @@ int batch_build(pw_batch* b) {
     pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
   }
   if (prule >= 0 && pfits && !b->use_f64 &&
+      !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd > 2048 && maxnd <= 64 * pw::kMaxWavesPerPair * 32 &&
+      !latency_mode && nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0 && !env_int("PWLIB_NO_PACKED_MW", 0)) {
+    // bands wider than one wavefront holds, many pairs (standard-mode tables of 1 .. 8 kb, say): the 16-bit body on a
+    // workgroup of up to 8 wavefronts per pair, as few diagonals per lane as 8 wavefronts allow
+    for (int i = 0; i < pw::kNumPackedBK; i++) {
+      const int bk = pw::kPackedBK[i];
+      if ((int64_t)64 * pw::kMaxWavesPerPair * bk >= maxnd) { pbk = bk; break; }
+    }
+    if (pbk) {
+      b->packed_nw = (maxnd + 64 * pbk - 1) / (64 * pbk);
+      pnl = 64 * b->packed_nw; pseg = 0;
+      b->variant = pw::VAR_FAST16;
+    }
+  }
+  else if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd <= 2048 &&
       nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0) {
     // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
@@ -452,7 +467,7 @@ int batch_build(pw_batch* b) {
       pw::WaveDesc wd;
       memset(&wd, 0, sizeof wd);
       wd.first = (int32_t)i; wd.count = (int32_t)std::min<size_t>(ppw, c.order.size() - i);
-      wd.nl = pseg ? pnl : 64;      // lanes per pair in the wave (the mask plane rows stay pnl wide)
+      wd.nl = (pseg || b->packed_nw > 1) ? pnl : 64;      // lanes per pair in the wave / workgroup (the mask plane rows stay pnl wide)
       wd.nblocks = 0; wd.steady_b0 = 0; wd.steady_b1 = 0x7fffffff;
       for (int q = 0; q < wd.count; q++) {
         const pw::PairDesc& d = b->descs[c.order[i + q]];
@@ -637,7 +652,8 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
   a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
   a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
   a.order = b->classes[0].d_order; a.waves = b->d_waves;
-  HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, (int)b->waves.size(), st));
+  if (b->packed_nw > 1) HIP_TRY(pw::launch_fill16_mw(a, b->classes[0].bk, b->packed_rule, b->packed_nw, (int)b->waves.size(), st));
+  else HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, (int)b->waves.size(), st));
   return 0;
 }
 
@@ -714,7 +730,8 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
   if (nw > 1) { snprintf(name, sizeof name, "k_fill_mw<%s, %d, ...> x %d wavefronts", t, bk, nw); return name; }
   switch (b->variant) {
     case pw::VAR_FAST16:
-      if (b->packed_rule == 3) snprintf(name, sizeof name, "k_fill16<%d, %s> x4", bk, b->packed_seg ? "true" : "false");
+      if (b->packed_nw > 1) snprintf(name, sizeof name, "k_fill16_mw<%d, %d> x %d wavefronts", bk, b->packed_rule, b->packed_nw);
+      else if (b->packed_rule == 3) snprintf(name, sizeof name, "k_fill16<%d, %s> x4", bk, b->packed_seg ? "true" : "false");
       else if (b->packed_rule) snprintf(name, sizeof name, "k_fill16<%d, %s, %d>", bk, b->packed_seg ? "true" : "false", b->packed_rule);
       else snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false");
       break;

@@ -470,6 +470,48 @@ def test_standard_mode_global_and_overlap_on_the_packed_kernels(oracle):
                 assert (runs[0][2][k] or '') == (r['transcript'] or ''), (alntype, k)
 
 
+def test_packed_body_on_several_wavefronts_per_pair(oracle):
+    """K2a with the 16-bit body (`k_fill16_mw`): batches of more than 256 pairs whose bands need 2049 .. 16 384 diagonals --
+    standard-mode tables of 1 .. 4 kb, wide bands on longer pairs -- for the four packed rules: records and transcripts equal
+    to the 32-bit kernels for every pair, a sample equal to the oracle (ragged lengths, unrelated pairs in the batch)."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(191)
+    cases = ((300, 1300, 0, 1, None, (1, -3, -5, -2), 'k_fill16_mw<8, 3>'), (300, 1100, 0, 0, None, (2, -3, -4, -1), 'k_fill16_mw<8, 2>'),
+             (280, 1500, 0, 4, None, (1, -1, -1, -1), 'k_fill16_mw<8, 1>'), (260, 4000, 1, 1, (-1500, 1400), (1, -3, -5, -2), 'k_fill16_mw<8, 0>'),
+             (260, 3000, 1, 2, (-2600, 2500), (1, -3, 0, -2), 'k_fill16_mw<12, 1>'))
+    for count, n, mode, alntype, band, sc, kernel in cases:
+        pairs = []
+        for k in range(count):
+            o = synth.rand_seqs(rng, 1, n if k % 7 else int(rng.integers(0, n)))[0]
+            m = synth.rand_seqs(rng, 1, n if k % 5 else int(rng.integers(1, n)))[0] if k % 3 == 0 else synth.mutate(rng, o, 0.05, 0.02, 0.4)
+            pairs.append((o, m))
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=4, match_score=sc[0], mismatch_score=sc[1], go_score=sc[2],
+                  ge_score=sc[3], check_band=False)
+        okw = dict(L=4, mode=mode, alntype=alntype, match=sc[0], mismatch=sc[1], go=sc[2], ge=sc[3])
+        if band is not None:
+            kw['diag_range'] = band; okw['diag_range'] = band
+        runs = []
+        for flags in (0, W.PW_FLAG_NO_PACKED16):
+            with BatchAligner(pairs, flags=flags, **kw) as b:
+                name = b.kernel_name
+                res = b.run()
+                runs.append((name, res.copy(), b.transcripts(res)))
+        assert kernel in runs[0][0], (runs[0][0], kernel)
+        assert 'k_fill16' not in runs[1][0]
+        assert (runs[0][1] == runs[1][1]).all() and runs[0][2] == runs[1][2], kernel
+        for k in range(0, count, 29):
+            r = oracle.solve(pairs[k][0], pairs[k][1], **okw)
+            if r['init_rc'] != 0:
+                continue
+            assert (runs[0][1]['opt_i'][k], runs[0][1]['opt_j'][k]) == r['opt'], (kernel, k)
+            if r['opt'][0] >= 0:
+                assert runs[0][1]['score'][k] == r['score'], (kernel, k)
+                if not r['would_panick']:
+                    assert (runs[0][2][k] or '') == (r['transcript'] or ''), (kernel, k)
+
+
 def test_traceback_from_explicit_end_cells(oracle):
     """dptable_traceback accepts any end cell (pw.c:116-123), not only the optimum."""
     from biseqt_amd.batch import BatchAligner
