@@ -667,6 +667,8 @@ struct WaveFill16 {
   // one unsigned maximum per cell pair instead of maximum, compare, subtract and multiply-add (H <= 8191: the planner
   // admits scores up to 8000); turned back into (best, step) once per block
   uint32_t kbE[RH], kbO[RH], C8, SH3, SEVEN, NEG2;
+  uint32_t up_prev;             // the lane below's last odd slot, as of the end of the previous iteration
+  int phase_l, phase_r;         // LDS slot of the next exchange to the left / right (multi-wavefront platforms)
 
   PW_FN WaveFill16(const FillParams<int32_t>& a_, const WaveDesc& wd_) : a(a_), wd(wd_) {}
 
@@ -751,7 +753,8 @@ struct WaveFill16 {
     const uint32_t tv0 = pk::both(2 * it), tv1 = pk::both(2 * it + 1);
     // even step: slot 0 <- previous lane's last slot, slot R <- own slot R - 1
     {
-      uint32_t prev = xshr1<P>(UO[RH - 1], NEGV);
+      // (the lane below's last odd slot: moved at the end of the previous iteration, together with the mutant window)
+      uint32_t prev = up_prev;
       if (SEG) prev = segfirst ? NEGV : prev;
       const uint32_t up0 = pk::align16(UO[RH - 1], prev);         // (prev.hi, own.lo)
 #pragma unroll
@@ -765,11 +768,18 @@ struct WaveFill16 {
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
     // Only cells outside the table read letters outside a sequence; in steady blocks those are out-of-band
     // slots whose values nobody reads, so the range check is needed in EDGE blocks only.
+    // The letter and the left offer of the odd step travel the same way: ONE exchange (platforms whose shifts cross
+    // wavefronts through LDS pay one barrier for the pair).
+    uint32_t nxt_left;
     {
       const int oi = xfeed_o + it;
       const uint32_t fb = Base::feed_byte(fo_lo, fo_hi, k);
       const uint32_t feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? fb : SENT_O;
-      uint32_t nxt = xshl1<P>(OW[0], feed);
+      int32_t mv[2] = {(int32_t)OW[0], (int32_t)LE[0]};
+      const int32_t mo[2] = {(int32_t)feed, (int32_t)NEGV};
+      xshlv<P, 2>(mv, mo, phase_l); phase_l ^= 1;
+      uint32_t nxt = (uint32_t)mv[0];
+      nxt_left = (uint32_t)mv[1];
       if (SEG) nxt = seglast ? feed : nxt;
       const uint32_t last = pk::align16(nxt, OW[0]);
 #pragma unroll
@@ -778,7 +788,7 @@ struct WaveFill16 {
     }
     // odd step: slot BK - 1 <- next lane's slot 0, slot R - 1 <- own slot R
     {
-      uint32_t nxt = xshl1<P>(LE[0], NEGV);
+      uint32_t nxt = nxt_left;
       if (SEG) nxt = seglast ? NEGV : nxt;
       const uint32_t leftl = pk::align16(nxt, LE[0]);              // (own.hi, next.lo)
 #pragma unroll
@@ -794,7 +804,12 @@ struct WaveFill16 {
       const int mi = yfeed_m + it;
       const uint32_t fbm = Base::feed_byte(fm_lo, fm_hi, k);
       const uint32_t feed = ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? fbm : SENT_M) << 16;
-      uint32_t prv = xshr1<P>(MW[RH - 1], feed);
+      // ... together with the up offer of the next iteration's even step (one exchange)
+      int32_t mv[2] = {(int32_t)MW[RH - 1], (int32_t)UO[RH - 1]};
+      const int32_t mo[2] = {(int32_t)feed, (int32_t)NEGV};
+      xshrv<P, 2>(mv, mo, phase_r); phase_r ^= 1;
+      uint32_t prv = (uint32_t)mv[0];
+      up_prev = (uint32_t)mv[1];
       if (SEG) prv = segfirst ? feed : prv;
       const uint32_t first = pk::align16(MW[RH - 1], prv);
 #pragma unroll
@@ -929,6 +944,7 @@ struct WaveFill16 {
       }
       tlE[p] = pk::pack(tlast_of(e0), tlast_of(e1)); tlO[p] = pk::pack(tlast_of(o0), tlast_of(o1));
       HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
+      up_prev = NEGV; phase_l = 0; phase_r = 0;
       // rule 0: scores never go below 0, and a diagonal whose best stays 0 reports its first cell (score 0 on the table edge)
       bestE[p] = bestO[p] = RL == 0 ? 0u : NEGV;
       btE[p] = RL == 0 ? tfE[p] : 0u; btO[p] = RL == 0 ? tfO[p] : 0u;
