@@ -240,6 +240,10 @@ int batch_build(pw_batch* b) {
   // tiled kernel, which like the strips takes the pairs one after another (0.43 us per anti-diagonal, whatever the width)
   auto wg_us_per_step_f64 = [](int ndiag) { return ndiag <= 1024 ? 0.47 : (ndiag <= 2048 ? 0.6 : (ndiag <= 4096 ? 1.0 : (ndiag <= 8192 ? 2.7 : 19.8))); };
   double est_tiles_ms = 0.0, est_wgroups_int_ms = 0.0, est_wgroups_f64_ms = 0.0;
+  // ... and the 16-bit body on several wavefronts per pair (k_fill16_mw), where the scores admit it
+  auto pmw_us_per_step = [](int ndiag) { return ndiag <= 4096 ? 0.38 : (ndiag <= 8192 ? 0.6 : 1.2); };
+  double est_pmw_ms = 0.0;
+  int min_x = 0x7fffffff;
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
   for (int32_t k = 0; k < b->n; k++) {
@@ -273,6 +277,8 @@ int batch_build(pw_batch* b) {
         est_tiles_ms += 0.05 + steps * 0.00043;
         est_wgroups_int_ms = std::max(est_wgroups_int_ms, steps * wg_us_per_step(pl.ndiag) * 1e-3);
         est_wgroups_f64_ms = std::max(est_wgroups_f64_ms, steps * wg_us_per_step_f64(pl.ndiag) * 1e-3);
+        est_pmw_ms = std::max(est_pmw_ms, steps * pmw_us_per_step(pl.ndiag) * 1e-3);
+        min_x = std::min(min_x, (int)p.origin_len);
       }
       if (b->mode == pw::STD_MODE) {
         const double X = p.origin_len, Y = p.mutant_len;
@@ -323,9 +329,15 @@ int batch_build(pw_batch* b) {
     const double highest = (double)maxmin * std::max(0.0, std::max(mt, mm));
     pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
   }
+  // (a few standard-mode pairs: the strips, one pair after another, when they are estimated to finish before the 16-bit body
+  //  on several wavefronts per pair would -- tests/micro/few_pairs.py: 2 kb x 2 kb, one pair 0.6 ms on the strips, 1.5 ms
+  //  there; four pairs 2.3 ms and 1.6 ms)
+  const bool strips_win = latency_mode && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
+                          !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) &&
+                          (double)maxspan * maxabs < (double)(1 << 25) && est_strips_ms < 0.9 * est_pmw_ms;
   if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd > 2048 && maxnd <= 64 * pw::kMaxWavesPerPair * 32 &&
-      !latency_mode && nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0 && !env_int("PWLIB_NO_PACKED_MW", 0)) {
+      nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0 && !env_int("PWLIB_NO_PACKED_MW", 0) && !strips_win) {
     // bands wider than one wavefront holds, many pairs (standard-mode tables of 1 .. 8 kb, say): the 16-bit body on a
     // workgroup of up to 8 wavefronts per pair, as few diagonals per lane as 8 wavefronts allow
     for (int i = 0; i < pw::kNumPackedBK; i++) {
@@ -370,8 +382,19 @@ int batch_build(pw_batch* b) {
     }
     else if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }
     else if (bk1) { pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 0; }
-    // one pair per wavefront with 16+ diagonals per lane is a long serial chain: small batches go multi-wavefront
-    if (latency_mode && pbk >= 16 && !pseg) pbk = 0;
+    // one pair per wavefront with 16+ diagonals per lane is a long serial chain: small batches go multi-wavefront --
+    // the strips if they win, else the 16-bit body on up to 8 wavefronts with 4 or 8 diagonals per lane
+    if (latency_mode && pbk >= 16 && !pseg) {
+      pbk = 0;
+      if (!strips_win && !forced && !env_int("PWLIB_NO_PACKED_MW", 0)) {
+        for (int i = 0; i < pw::kNumPackedBK; i++) {
+          const int bk = pw::kPackedBK[i];
+          if ((int64_t)64 * pw::kMaxWavesPerPair * bk >= maxnd) { pbk = bk; break; }
+        }
+        if (pbk) { b->packed_nw = (maxnd + 64 * pbk - 1) / (64 * pbk); pnl = 64 * b->packed_nw; pseg = 0; }
+        if (b->packed_nw <= 1) { pbk = 0; b->packed_nw = 1; }      // (one wavefront would do: not this case)
+      }
+    }
     if (pbk) b->variant = pw::VAR_FAST16;
   }
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----

@@ -786,9 +786,11 @@ def test_wide_pairs_single_wavefront_and_latency_mode(oracle, latency_mode, monk
             # (f64 with 32 diagonals per lane does not fit one wavefront's registers: several wavefronts in any mode)
             assert ('k_fill_mw' not in name or (flags & W.PW_FLAG_FORCE_F64 and ndiag > 1024)) and 'strip' not in name, name
         elif strip_ok:
-            assert 'k_fill_strip' in name, (name, ndiag)     # a couple of pairs: row strips, one pair after another
+            # a couple of pairs: row strips, one pair after another -- or the 16-bit body on several wavefronts per pair
+            assert 'k_fill_strip' in name or 'k_fill16_mw' in name, (name, ndiag)
         elif ndiag > 1024:                       # (up to 64 x 12 diagonals the packed one-wavefront kernel may still win)
-            assert 'k_fill_mw' in name or 'tile' in name, (name, ndiag)    # several wavefronts, or the tiled kernel for one pair
+            # several wavefronts (32-bit or 16-bit body), or the tiled kernel for one pair
+            assert 'k_fill_mw' in name or 'k_fill16_mw' in name or 'tile' in name, (name, ndiag)
         r = oracle.solve(o, m, **okw)
         assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'], (n, mode, alntype, name)
         if r['opt'][0] != -1:
