@@ -146,6 +146,8 @@ def run(budget, seed, long_mode=False, max_batches=None):
         if time.time() - last > 30:
             last = time.time()
             print('... %d batches, %d pairs, %d bad' % (nb, npairs, nbad), flush=True)
+    for name in ('PWLIB_LATENCY_MODE', 'PWLIB_NO_SCALED16'):      # (the knobs must not outlive the run: pytest calls it in-process)
+        os.environ.pop(name, None)
     print('kernels: ' + ', '.join('%s x%d' % kv for kv in sorted(kernels.items(), key=lambda kv: -kv[1])))
     print('fuzz: %d batches, %d pairs, %d mismatches (seed %d, %.0f s)' % (nb, npairs, nbad, seed, time.time() - t0))
     return nb, npairs, nbad
