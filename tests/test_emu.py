@@ -101,7 +101,7 @@ def test_emu_packed16_local(oracle):
         m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 9))).astype(np.uint8)
         if rng.random() < 0.3:
             m = np.concatenate([rng.integers(0, L, int(rng.integers(0, 30))).astype(np.uint8), m])
-        kw = dict(L=L, match=float(rng.choice([1, 2, 5])), mismatch=float(rng.choice([0, -1, -3, 6])),   # also mismatch > match
+        kw = dict(L=L, match=float(rng.choice([1, 2, 5, 5, -1])), mismatch=float(rng.choice([0, -1, -3, 6])),   # also mismatch > match, match < 0
                   go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
         if rng.random() < 0.7:
             r, c = int(rng.integers(1, 50)), int(rng.integers(-10, 10))
@@ -117,8 +117,8 @@ def test_emu_packed16_local(oracle):
         b = emu.solve(o, m, bk=bk, packed16=1 + trial % 2, **kw)   # 1: lane-packed form, 2: one pair per wave
         for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
             assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk)
-        if min(X, len(m)) * max(kw['match'], kw['mismatch'], 0) <= 2047:
-            # 3: every score held times 4 (tie nibble by one three-operand add; admitted below 2048)
+        if kw['match'] >= 0 and min(X, len(m)) * max(kw['match'], kw['mismatch'], 0) <= 2047:
+            # 3: every score held times 4 (tie nibble by one three-operand add; admitted below 2048, match score >= 0)
             for pk in (3, 4):                                         # 4: the lane-packed form of it
                 c = emu.solve(o, m, bk=bk, packed16=pk, **kw)
                 for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
