@@ -22,6 +22,7 @@ from oracle import oracle as O                     # noqa: E402
 SCORES = [(1, -3, -5, -2), (1, 0, 0, 0), (2, -1, 0, -1), (5, -4, -10, -1), (1, -1, -1, -1), (3, -2, 3, -4),
           (1, -1, 2, -3), (100, -100, -100, -100), (0, 0, 0, 0), (1, -3, 0, -2), (2, -3, -5, 0),
           (1, 6, -5, -2), (2, 3, -1, -1),      # mismatch > match: the API accepts it
+          (-1, -2, -3, -1), (-1, 2, -2, -1), (-2, 0, -1, 0),   # ... and a negative match score
           (0.5, -0.25, -1.5, -0.75), (1.3862943611198906, -0.8754687373538999, -2.995732273553991, -0.6931471805599453)]
 FLAGS = [0, 0, 0, W.PW_FLAG_NO_PACKED16, W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_GENERIC, W.PW_FLAG_FORCE_TILED,
          W.PW_FLAG_FORCE_TILED | W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_STRIP, W.PW_FLAG_FORCE_STRIP]
