@@ -430,6 +430,57 @@ def test_scaled_packed_kernel_at_its_admission_bound(oracle):
             assert runs[0][1]['score'][0] == n * match
 
 
+def test_negative_match_score_on_the_packed_kernels(oracle):
+    """The API takes any scores (/root/reference/biseqt/pw.py:185-196 only builds the matrix): a NEGATIVE match score with
+    a worse, an equal or a better mismatch score, on the packed kernels of every rule (B_LOCAL, B_OVERLAP, B_GLOBAL,
+    standard-mode GLOBAL) -- each batch must equal the 32-bit kernel pair for pair and the oracle on a sample."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(911)
+    seen = set()
+    for (match, mismatch, go, ge) in ((-1, -2, -3, -1), (-1, 2, -2, -1), (-2, 0, -1, 0), (-1, -1, 0, -1)):
+        for mode, alntype, dr in ((1, 1, (-12, 9)), (1, 2, (-30, 25)), (1, 0, (-20, 20)), (0, 0, None)):
+            pairs = []
+            for _ in range(300):                                # enough pairs to leave latency mode
+                n = int(rng.integers(20, 400 if mode else 180))
+                o = synth.rand_seqs(rng, 1, n)[0]
+                pairs.append((o, synth.mutate(rng, o, 0.06, 0.03, 0.4)))
+            kw = dict(alnmode=mode, alntype=alntype, alphabet_len=4, match_score=match, mismatch_score=mismatch,
+                      go_score=go, ge_score=ge, check_band=False)   # short pairs: the C side clamps the band like dptable_init
+            if dr is not None:
+                kw['diag_range'] = dr
+            with BatchAligner(pairs, **kw) as b:
+                name = b.kernel_name
+                res = b.run().copy()
+                txs = b.transcripts(res)
+                rcs = [b.init_rc(k) for k in range(len(pairs))]
+            with BatchAligner(pairs, flags=W.PW_FLAG_NO_PACKED16, **kw) as b:
+                assert 'k_fill16' not in b.kernel_name
+                res2 = b.run().copy()
+                txs2 = b.transcripts(res2)
+            assert 'k_fill16' in name, (name, kw)
+            seen.add(name)
+            assert (res == res2).all() and txs == txs2, (name, kw)
+            for k in range(0, len(pairs), 23):
+                r = oracle.solve(pairs[k][0], pairs[k][1], L=4, mode=mode, alntype=alntype, diag_range=dr, match=match,
+                                 mismatch=mismatch, go=go, ge=ge)
+                where = (k, name, kw)
+                assert rcs[k] == r['init_rc'], where
+                if r['init_rc'] != 0:
+                    continue
+                assert (int(res['opt_i'][k]), int(res['opt_j'][k])) == tuple(r['opt']), where
+                if res['opt_i'][k] == -1:
+                    continue
+                st = int(res['status'][k])
+                assert res['score'][k] == r['score'], where
+                assert bool(st & W.PW_ST_PANICK) == bool(r['would_panick']), where
+                if not (st & (W.PW_ST_PANICK | W.PW_ST_EMPTY)):
+                    assert txs[k] == r['transcript'], where
+                    assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx']), where
+    assert len(seen) >= 3, seen                                  # rules 0 (scaled), 1 and 2
+
+
 def test_standard_mode_global_and_overlap_on_the_packed_kernels(oracle):
     """Standard-mode GLOBAL and OVERLAP batches take the packed rule-2 / rule-1 kernels -- the global / overlap rules on the
     band [-Y, X], OVERLAP with its own order of ties among the last cells -- and must equal the 32-bit kernel for every pair
