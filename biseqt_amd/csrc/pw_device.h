@@ -151,8 +151,21 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
 }
 
 // Lane-packed 16-bit kernel: one wavefront = WaveDesc.count pairs side by side (pw_wave.h, WaveFill16).
+// Occupancy: left to itself the max-ilp schedule of the BK = 8 one-pair-per-wavefront body takes 157-164 VGPRs (3
+// wavefronts per SIMD); held to 5 per SIMD it needs 87-96 without a spill and config 2 runs 1.3-2 % faster
+// (tests/micro/ab_k1.sh: 2132 -> 2160-2178 GCUPS; 4 per SIMD: 2139-2147).  The other instantiations keep the default
+// bounds (at 5 the lane-packed BK = 8 body would spill 35 registers, the overlap / global rules 2).
+#ifndef PW_FILL16_WAVES
+#define PW_FILL16_WAVES 5
+#endif
+template <int BK, bool SEG, int RULE> struct Fill16Occupancy {
+  static constexpr bool held = BK == 8 && !SEG && (RULE == 0 || RULE == 3) && PW_FILL16_WAVES > 0;
+  static constexpr unsigned lo = held ? PW_FILL16_WAVES : 1, hi = held ? PW_FILL16_WAVES : 8;
+};
 template <int BK, bool SEG, int RULE>
-__global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill16(const FillParams<int32_t> a) {
+__global__ __launch_bounds__(64) PW_FILL_ATTR
+__attribute__((amdgpu_waves_per_eu(Fill16Occupancy<BK, SEG, RULE>::lo, Fill16Occupancy<BK, SEG, RULE>::hi)))
+void k_fill16(const FillParams<int32_t> a) {
   const WaveDesc wd = a.waves[blockIdx.x];
   WaveFill16<DevP, BK, SEG, RULE> w(a, wd);
   w.run();
