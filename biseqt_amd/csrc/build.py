@@ -25,6 +25,16 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract
           '-Wno-unused-function'] + os.environ.get('PW_EXTRA_CXXFLAGS', '').split()
 BKS = (2, 4, 8, 16, 32)
 PACKED_BKS = (4, 8, 12, 16, 20, 24, 28, 32)
+# Wavefronts per SIMD the packed kernels are held to, (bk, rule) -> (one pair per wavefront, lane-packed); absent / 0 =
+# the compiler's default.  The max-ilp schedule spends registers freely; a bound makes it fit fewer.  Only the entries
+# measured faster are listed (tests/micro/ab_occupancy.sh): BK = 8 local rules 157 -> 87 VGPRs, config 2 fill 1-2 % and
+# the pipelined step 3 % faster; BK = 16 local rules 177 -> 165 VGPRs, 2.8 % on an 801-diagonal band.  Every other
+# instantiation compiled without a spill at one more wavefront per SIMD too, and ran the same within 2 % -- or slower: the
+# lane-packed BK = 4 body at 4 per SIMD (169 -> 109 VGPRs) lost 24-35 % on 20 000 pairs with a 21-diagonal band.
+FILL16_WAVES = {
+    (8, 0): (5, 0), (8, 3): (5, 0),
+    (16, 0): (3, 0), (16, 3): (3, 0),
+}
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
 
@@ -49,7 +59,9 @@ def _jobs():
         obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d_r%d.o' % (bk, rule))
         # max-ilp scheduling: dependent VOP3P ops need a wait state between them; the default (occupancy first)
         # schedule leaves ~15% of the issue slots of the packed kernel to s_nop, this one none (measured)
-        cmd = [HIPCC] + COMMON + ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-DPW_BK=%d' % bk, '-DPW_RULE=%d' % rule, '-c',
+        occ, occ_seg = FILL16_WAVES.get((bk, rule), (0, 0)) if os.environ.get('PW_FILL16_OCCUPANCY', '1') != '0' else (0, 0)
+        cmd = [HIPCC] + COMMON + ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-DPW_BK=%d' % bk, '-DPW_RULE=%d' % rule,
+                                  '-DPW_FILL16_WAVES=%d' % occ, '-DPW_FILL16_WAVES_SEG=%d' % occ_seg, '-c',
                os.path.join(HERE, 'pw_fill16_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill16_tu.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_trace.o')

@@ -151,16 +151,20 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
 }
 
 // Lane-packed 16-bit kernel: one wavefront = WaveDesc.count pairs side by side (pw_wave.h, WaveFill16).
-// Occupancy: left to itself the max-ilp schedule of the BK = 8 one-pair-per-wavefront body takes 157-164 VGPRs (3
-// wavefronts per SIMD); held to 5 per SIMD it needs 87-96 without a spill and config 2 runs 1.3-2 % faster
-// (tests/micro/ab_k1.sh: 2132 -> 2160-2178 GCUPS; 4 per SIMD: 2139-2147).  The other instantiations keep the default
-// bounds (at 5 the lane-packed BK = 8 body would spill 35 registers, the overlap / global rules 2).
+// Occupancy: left to itself the max-ilp schedule spends registers freely (the BK = 8 one-pair-per-wavefront body takes
+// 157-164 VGPRs: 3 wavefronts per SIMD); held to 5 per SIMD it needs 87-96 without a spill and config 2 runs 1.3-2 %
+// faster (tests/micro/ab_k1.sh: 2132 -> 2160-2178 GCUPS; 4 per SIMD: 2139-2147).  build.py passes the bound of each
+// instantiation (PW_FILL16_WAVES: one pair per wavefront, PW_FILL16_WAVES_SEG: lane-packed; 0 = the compiler's default)
+// -- only where the held schedule does not spill and was measured faster.
 #ifndef PW_FILL16_WAVES
-#define PW_FILL16_WAVES 5
+#define PW_FILL16_WAVES 0
+#endif
+#ifndef PW_FILL16_WAVES_SEG
+#define PW_FILL16_WAVES_SEG 0
 #endif
 template <int BK, bool SEG, int RULE> struct Fill16Occupancy {
-  static constexpr bool held = BK == 8 && !SEG && (RULE == 0 || RULE == 3) && PW_FILL16_WAVES > 0;
-  static constexpr unsigned lo = held ? PW_FILL16_WAVES : 1, hi = held ? PW_FILL16_WAVES : 8;
+  static constexpr unsigned w = SEG ? PW_FILL16_WAVES_SEG : PW_FILL16_WAVES;
+  static constexpr unsigned lo = w ? w : 1, hi = w ? w : 8;
 };
 template <int BK, bool SEG, int RULE>
 __global__ __launch_bounds__(64) PW_FILL_ATTR
