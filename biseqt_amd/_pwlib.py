@@ -101,12 +101,13 @@ class pw_result(C.Structure):
                 ('tx_len', C.c_int32), ('status', C.c_int32)]
 
 
-PW_ST_TRACED, PW_ST_EMPTY, PW_ST_PANICK = 1, 2, 4
+PW_ST_TRACED, PW_ST_EMPTY, PW_ST_PANICK, PW_ST_BADPATH = 1, 2, 4, 8
 PW_FLAG_DUMP_SCORES, PW_FLAG_FORCE_F64, PW_FLAG_FORCE_GENERIC, PW_FLAG_PROFILE = 1, 2, 4, 8
 PW_FLAG_NO_PACKED16 = 16
 PW_FLAG_FORCE_TILED = 32
 PW_FLAG_FORCE_STRIP = 64
 PW_FLAG_SHARED_ARENA = 128
+PW_FLAG_NO_STRIP = 256
 
 SIZEOF = dict(intpair=8, alnscores=24, alnframe=32, std_alnparams=4, banded_alnparams=12,
               alnprob=32, alnchoice=32, dpcell=16, dptable=32, alignment=24,

@@ -83,11 +83,26 @@ def _jobs():
     return jobs
 
 
-def _stale(target, deps):
+def _cmd_text(cmd):
+    return ' '.join(cmd) + '\n'
+
+
+def _stale(target, deps, cmd=None):
+    """Out of date when a dependency is newer OR the command line differs from the one that built the object (kept beside
+    it as `<object>.cmd`): the build-time knobs -- PW_FILL16_OCCUPANCY, FILL16_WAVES, PW_EXTRA_CXXFLAGS, PW_TILE_* --
+    change the command but no file, and an A/B of two settings in one PW_OBJ_DIR must not compare two identical binaries."""
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    if cmd is not None:
+        try:
+            with open(target + '.cmd') as f:
+                return f.read() != _cmd_text(cmd)
+        except OSError:
+            return True
+    return False
 
 
 def build(force=False, verbose=True):
@@ -95,11 +110,16 @@ def build(force=False, verbose=True):
     os.makedirs(OUT_DIR, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     jobs = _jobs()
-    todo = [(o, c) for (o, c, deps) in jobs if force or _stale(o, deps + hdrs + [os.path.abspath(__file__)])]
+    todo = [(o, c) for (o, c, deps) in jobs if force or _stale(o, deps + hdrs, c)]
 
     def run(job):
         obj, cmd = job
+        if os.path.exists(obj + '.cmd'):
+            os.remove(obj + '.cmd')
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+        if r.returncode == 0:
+            with open(obj + '.cmd', 'w') as f:
+                f.write(_cmd_text(cmd))
         return obj, r.returncode, r.stdout
 
     workers = max(1, min(len(todo), (os.cpu_count() or 4)))
@@ -113,6 +133,15 @@ def build(force=False, verbose=True):
                 if verbose and out.strip():
                     print(out)
     objs = [o for (o, _, _) in jobs]
+    # The strip kernel's hand-over loads land in accumulation registers a0..a3 behind the compiler's back (pw_strip.hip):
+    # refuse a build in which the compiler allocated AGPRs of its own there, or spilled (codeobj.strip_kernel_violations)
+    strip_obj = os.path.join(OBJ_DIR, 'pw_strip.o')
+    if force or any(o == strip_obj for o, _ in todo) or not os.path.exists(SO):
+        from . import codeobj
+        bad = codeobj.strip_kernel_violations(strip_obj)
+        if bad:
+            os.remove(strip_obj)
+            raise RuntimeError('pw_strip.o breaks the invariants its inline asm relies on:\n  ' + '\n  '.join(bad))
     if force or todo or _stale(SO, objs):
         cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', SO]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)

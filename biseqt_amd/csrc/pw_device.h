@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_tile_finish(const FillParams<T> a, cons
   }
   if (threadIdx.x == 0) {
     Result r;
-    r.score = (double)s_s[0];
+    r.score = (double)s_s[0] * a.score_mul;
     r.opt_i = a.banded ? s_x[0] - s_y[0] - pd.dmin : s_x[0];
     r.opt_j = a.banded ? (s_x[0] < s_y[0] ? s_x[0] : s_y[0]) : s_y[0];
     r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;

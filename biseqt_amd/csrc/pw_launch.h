@@ -56,7 +56,7 @@ struct StripTraceParams;
 hipError_t launch_strip_fill(const StripParams& a, bool track, int nworkers, int lds_bytes, hipStream_t st);
 hipError_t launch_strip_trace(const StripTraceParams& p, hipStream_t st);
 hipError_t launch_xcc_census(uint32_t* d_seen8, hipStream_t st);
-hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double* out, hipStream_t st);
+hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double mul, double* out, hipStream_t st);
 
 }  // namespace pw
 #endif

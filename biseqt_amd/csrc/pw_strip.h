@@ -57,6 +57,7 @@ struct StripParams {
   int32_t brule, endrule;
   int32_t match, mismatch, go, ge;
   int32_t spin_limit;        // polls of one FIFO chunk before giving up
+  double score_mul;          // reported score = the kernel's integer value times this (dyadic scaling, pw_types.h)
   // Placement (speed and store flavour only): strips are dealt in RUNS of run_len consecutive strips; run r is worked
   // on by the wavefronts of ONE XCD (queue r mod nq), so that a strip and the strip above it normally share an L2 and the
   // FIFO between them never leaves it (plain stores, L2-served loads).  Only the last strip of a run hands over to another
@@ -518,7 +519,7 @@ PW_FN void strip_reduce(const StripParams& a) {
   }
   if (lane == 0) {
     Result r;
-    r.score = (double)cs; r.opt_i = cx; r.opt_j = cy;          // standard mode: table coordinates are (x, y)
+    r.score = (double)cs * a.score_mul; r.opt_i = cx; r.opt_j = cy;          // standard mode: table coordinates are (x, y)
     r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;
     // LOCAL / START_ANCHORED start from the score of cell (0,0), i.e. 0 (_pw_internals.c:342)
     if (!hv || (a.endrule == END_STD_LOCAL && !(cs > 0))) { r.opt_i = -1; r.opt_j = -1; r.score = 0.0; }

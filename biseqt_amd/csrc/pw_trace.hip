@@ -76,17 +76,17 @@ __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
 // Standard-mode score plane [d - dmin][a] -> the reference's row-major table [x][y] as doubles (what the drop-in
 // materialises for Aligner.table_scores, pw.py:278-285): coalesced writes, the strided reads stay on the device.
 template <typename T>
-__global__ __launch_bounds__(256) void k_table_rowmajor(const T* __restrict__ plane, int X, int Y, int pitch, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_table_rowmajor(const T* __restrict__ plane, int X, int Y, int pitch, double mul, double* __restrict__ out) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= (int64_t)(X + 1) * (Y + 1)) return;
   const int x = (int)(c / (Y + 1)), y = (int)(c - (int64_t)x * (Y + 1));
-  out[c] = (double)plane[(int64_t)(x - y + Y) * pitch + (x < y ? x : y)];
+  out[c] = (double)plane[(int64_t)(x - y + Y) * pitch + (x < y ? x : y)] * mul;   // (mul: dyadic scaling, a power of two)
 }
-hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double* out, hipStream_t st) {
+hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double mul, double* out, hipStream_t st) {
   const int64_t n = (int64_t)(X + 1) * (Y + 1);
   const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-  if (f64) hipLaunchKernelGGL((k_table_rowmajor<double>), grid, blk, 0, st, (const double*)plane, X, Y, pitch, out);
-  else hipLaunchKernelGGL((k_table_rowmajor<int32_t>), grid, blk, 0, st, (const int32_t*)plane, X, Y, pitch, out);
+  if (f64) hipLaunchKernelGGL((k_table_rowmajor<double>), grid, blk, 0, st, (const double*)plane, X, Y, pitch, mul, out);
+  else hipLaunchKernelGGL((k_table_rowmajor<int32_t>), grid, blk, 0, st, (const int32_t*)plane, X, Y, pitch, mul, out);
   return hipGetLastError();
 }
 

@@ -106,6 +106,9 @@ struct FillParams {
   int32_t banded;             // results are reported in (d - dmin, a) table coordinates
   T match, mismatch;          // simple scoring (fast kernels)
   T go, ge;
+  // Dyadic scaling (host planner): scores that are multiples of 2^-k are held times 2^k by the integer kernels; the
+  // reported score is the kernel's value times score_mul = 2^-k (exact).  1.0 otherwise.
+  double score_mul;
 };
 
 struct TraceParams {

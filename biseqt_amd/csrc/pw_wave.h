@@ -520,7 +520,7 @@ struct WaveFill {
     }
     if (lane == 0) {
       Result r;
-      r.score = (double)cs;
+      r.score = (double)cs * a.score_mul;
       // table coordinates as dptable_solve returns them (_cellpos_from_xy, _pw_internals.c:87-98)
       r.opt_i = a.banded ? cx - cy - pd.dmin : cx;
       r.opt_j = a.banded ? (cx < cy ? cx : cy) : cy;
@@ -1035,7 +1035,7 @@ struct WaveFill16 {
       }
       if (seg == sidx && li == 0) {
         Result r;
-        r.score = (double)rs;
+        r.score = (double)rs * a.score_mul;
         r.opt_i = a.banded ? rx - ry - pd.dmin : rx;
         r.opt_j = a.banded ? (rx < ry ? rx : ry) : ry;
         r.origin_idx = 0; r.mutant_idx = 0; r.tx_len = 0; r.status = 0;

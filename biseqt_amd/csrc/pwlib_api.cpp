@@ -150,6 +150,8 @@ struct pw_batch {
   double go = 0, ge = 0;
   std::vector<double> subst;
   bool simple = false, use_f64 = false;
+  int scale_shift = 0;                   // dyadic scaling: every score is held times 2^scale_shift by the integer kernels
+  double score_mul = 1.0;                // 2^-scale_shift: what the kernels multiply a reported score with
   int variant = 0, brule = 0, endrule = 0, gosign = 0;
   std::vector<pw_pair> pairs;
   std::vector<pw::Plan> plans;
@@ -178,12 +180,21 @@ struct pw_batch {
   int32_t* d_ends = nullptr;
   hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr, ev_tr0 = nullptr, ev_tr1 = nullptr;
   bool fill_timed = false, trace_timed = false;
+  // scores as the caller gave them (batch_build may scale b->subst / go / ge by a power of two)
+  std::vector<double> subst_in; double go_in = 0, ge_in = 0;
+  // Strip pairs whose pipeline gave up waiting (PW_ST_BADPATH with no end cell) are solved again by a batch of one with the
+  // strips disabled (repair_strip_pair); the replacement lives as long as the batch and serves every later traceback
+  std::vector<std::pair<int32_t, pw_batch*>> repaired;
+  bool traced = false, traced_from = false;          // what the last traceback call was (a repaired pair repeats it)
+  std::vector<int32_t> last_ends;
 };
 
 namespace {
 
 int batch_free_device(pw_batch* b) {
   if (!b) return 0;
+  for (auto& r : b->repaired) pw_batch_destroy(r.second);
+  b->repaired.clear();
   (void)hipSetDevice(b->device);
   // the buffers are parked for the next batch, not freed (hipFree would synchronise by itself): make sure nothing that
   // was launched on any stream still reads or writes them
@@ -219,14 +230,37 @@ int batch_build(pw_batch* b) {
   bool integral = is_integral(b->go) && is_integral(b->ge);
   double maxabs = std::max(fabs(b->go), std::max(fabs(b->ge), fabs(b->go + b->ge)));
   b->simple = true;
-  const double mt = b->subst[0], mm = L > 1 ? b->subst[1] : b->subst[0];
-  for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) {
-    const double v = b->subst[(size_t)i * L + j];
-    if (!(v == v) || fabs(v) > 1e300) return fail("substitution scores must be finite");
-    integral = integral && is_integral(v);
-    maxabs = std::max(maxabs, fabs(v));
-    if (v != (i == j ? mt : mm)) b->simple = false;
+  {
+    const double mt0 = b->subst[0], mm0 = L > 1 ? b->subst[1] : b->subst[0];
+    for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) {
+      const double v = b->subst[(size_t)i * L + j];
+      if (!(v == v) || fabs(v) > 1e300) return fail("substitution scores must be finite");
+      integral = integral && is_integral(v);
+      maxabs = std::max(maxabs, fabs(v));
+      if (v != (i == j ? mt0 : mm0)) b->simple = false;
+    }
   }
+  // Dyadic scaling: scores that are all multiples of 2^-k (k <= 10; e.g. config 5's extension scores 0.25 / -1 / 0 / -1,
+  // reference experiments/blot_stats.py:365-372) are held times 2^k and run on the integer kernels.  Every partial sum of
+  // such scores is exact in the reference's doubles (the planner keeps them far below 2^53 / 2^k), scaling by a power of
+  // two preserves every comparison and tie, and the kernels report value * 2^-k, which is exact again: bit-identical
+  // results, no f64 kernel.  PW_FLAG_FORCE_F64 and PWLIB_NO_DYADIC=1 keep the scores as given.
+  if (!integral && !(b->flags & PW_FLAG_FORCE_F64) && !env_int("PWLIB_NO_DYADIC", 0) && maxabs < 1e6) {
+    for (int sh = 1; sh <= 10 && !b->scale_shift; sh++) {
+      const double f = (double)(1 << sh);
+      bool ok = is_integral(b->go * f) && is_integral(b->ge * f);
+      for (size_t i = 0; ok && i < b->subst.size(); i++) ok = is_integral(b->subst[i] * f);
+      if (ok) b->scale_shift = sh;
+    }
+    if (b->scale_shift) {
+      const double f = (double)(1 << b->scale_shift);
+      for (auto& v : b->subst) v *= f;
+      b->go *= f; b->ge *= f;
+      b->score_mul = 1.0 / f;
+      integral = true; maxabs *= f;
+    }
+  }
+  const double mt = b->subst[0], mm = L > 1 ? b->subst[1] : b->subst[0];
   pw::plan_rules(b->mode, b->type, &b->brule, &b->endrule);
   b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
   // ---- pass 1: per-pair plans (dptable_init arithmetic) and batch statistics ----
@@ -333,7 +367,7 @@ int batch_build(pw_batch* b) {
   //  on several wavefronts per pair would -- tests/micro/few_pairs.py: 2 kb x 2 kb, one pair 0.6 ms on the strips, 1.5 ms
   //  there; four pairs 2.3 ms and 1.6 ms)
   const bool strips_win = latency_mode && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
-                          !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) &&
+                          !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) && !(b->flags & PW_FLAG_NO_STRIP) &&
                           (double)maxspan * maxabs < (double)(1 << 25) && est_strips_ms < 0.9 * est_pmw_ms;
   if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd > 2048 && maxnd <= 64 * pw::kMaxWavesPerPair * 32 &&
@@ -406,7 +440,7 @@ int batch_build(pw_batch* b) {
     // (scores within +-2^25: the strip kernel tracks a row's best as 32 * H + step)
     const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && (double)maxspan * maxabs < (double)(1 << 25) &&
                           b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
-                          !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED)) && !env_int("PWLIB_NO_STRIP", 0);
+                          !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED | PW_FLAG_NO_STRIP)) && !env_int("PWLIB_NO_STRIP", 0);
     // ... always for tables wider than a workgroup holds; and for batches of a few pairs (at most 256: latency mode) when the
     // strips of all pairs, one pair after another, are estimated to finish before the slowest workgroup would (2 kb x 2 kb:
     // 0.6 ms per pair against 13.6 ms for one workgroup of 32-diagonal lanes -- up to 16 such pairs; 1 kb x 1 kb: 0.3 ms
@@ -606,6 +640,7 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
     a.brule = b->brule; a.endrule = b->endrule;
     a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
     a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
+    a.score_mul = b->score_mul;
     a.spin_limit = env_int("PWLIB_STRIP_SPIN_LIMIT", 1 << 21);
     a.nq = xcc_queues(b->device, a.xcc_queue);
     if (a.nq <= 0) return fail("could not determine the XCDs of the device");
@@ -642,6 +677,7 @@ int launch_all_fills(pw_batch* b, hipStream_t st) {
   a.banded = b->mode == pw::BANDED_MODE;
   a.match = (T)b->subst[0]; a.mismatch = (T)(b->L > 1 ? b->subst[1] : b->subst[0]);
   a.go = (T)b->go; a.ge = (T)b->ge;
+  a.score_mul = b->score_mul;
   for (auto& c : b->classes) {
     a.order = c.d_order;
     if (c.nw > 1) HIP_TRY(pw::launch_fill_mw(a, b->variant, c.bk, c.nw, (int)c.order.size(), st));
@@ -674,6 +710,7 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
   a.banded = b->mode == pw::BANDED_MODE;
   a.match = (int32_t)b->subst[0]; a.mismatch = (int32_t)(b->L > 1 ? b->subst[1] : b->subst[0]);
   a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
+  a.score_mul = b->score_mul;
   a.order = b->classes[0].d_order; a.waves = b->d_waves;
   if (b->packed_nw > 1) HIP_TRY(pw::launch_fill16_mw(a, b->classes[0].bk, b->packed_rule, b->packed_nw, (int)b->waves.size(), st));
   else HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, (int)b->waves.size(), st));
@@ -713,6 +750,7 @@ pw_batch* pw_batch_create(int device, const pw_scoring* sc, int32_t n_pairs, con
   b->device = device; b->n = n_pairs; b->flags = flags;
   b->mode = sc->mode; b->type = sc->type; b->L = sc->alphabet_len; b->go = sc->go; b->ge = sc->ge;
   b->subst.assign(sc->subst, sc->subst + (size_t)b->L * b->L);
+  b->subst_in = b->subst; b->go_in = b->go; b->ge_in = b->ge;
   b->pairs.assign(pairs, pairs + n_pairs);
   b->arena_bytes = arena_bytes;
   if (batch_build(b) != 0) { batch_free_device(b); delete b; return nullptr; }
@@ -821,12 +859,56 @@ int pw_batch_solve(pw_batch* b, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (b->arena_shared && !b->d_arena) return fail("pw_batch_solve: the batch was created with PW_FLAG_SHARED_ARENA and has no arena yet");
   HIP_TRY(hipSetDevice(b->device));
+  b->traced = false; b->traced_from = false;
+  if (!b->repaired.empty()) {          // a new solve: the strips get another chance
+    HIP_TRY(hipDeviceSynchronize());
+    for (auto& r : b->repaired) pw_batch_destroy(r.second);
+    b->repaired.clear();
+  }
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_fill0, st));
   int rc = b->variant == pw::VAR_FAST16 ? launch_packed_fill(b, st)
            : b->use_f64 ? launch_all_fills<double>(b, st) : launch_all_fills<int32_t>(b, st);
   if (rc == 0 && !b->strips.empty()) rc = launch_strip_fills(b, st);
   if (rc != 0) return rc;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_fill1, st)); b->fill_timed = true; }
+  return 0;
+}
+
+static pw_batch* repaired_sub(pw_batch* b, int32_t k) {
+  for (auto& r : b->repaired) if (r.first == k) return r.second;
+  return nullptr;
+}
+
+// The replacement of a repaired strip pair repeats the batch's last traceback call; its record and transcript slot (same
+// capacity, ops right-aligned) are copied over the pair's own, device to device, on the same stream.
+static int replay_trace(pw_batch* b, int32_t k, pw_batch* sub, hipStream_t st) {
+  if (b->traced_from) {
+    const int32_t e[2] = {b->last_ends[2 * (size_t)k], b->last_ends[2 * (size_t)k + 1]};
+    if (pw_batch_traceback_from(sub, e, st) != 0) return -1;
+  } else if (pw_batch_traceback(sub, st) != 0) return -1;
+  const pw::PairDesc& d = b->descs[k];
+  HIP_TRY(hipMemcpyAsync(b->d_results + k, sub->d_results, sizeof(pw::Result), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(b->d_tx + d.tx_off, sub->d_tx + sub->descs[0].tx_off, (size_t)d.tx_cap, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// A strip pair whose pipeline was abandoned (a wavefront waited longer than PWLIB_STRIP_SPIN_LIMIT polls for the strip above
+// it: a starved or contended device) is solved once more inside the library, as a batch of one that shares the arena and
+// may not use the strips (tiled or workgroup kernels).  Synchronous; called from pw_batch_results.
+static int repair_strip_pair(pw_batch* b, int32_t k) {
+  pw_scoring sc;
+  sc.mode = b->mode; sc.type = b->type; sc.alphabet_len = b->L; sc.subst = b->subst_in.data(); sc.go = b->go_in; sc.ge = b->ge_in;
+  const uint32_t keep = b->flags & (PW_FLAG_FORCE_F64 | PW_FLAG_FORCE_GENERIC | PW_FLAG_NO_PACKED16);
+  pw_batch* sub = pw_batch_create(b->device, &sc, 1, &b->pairs[k], b->arena_bytes, keep | PW_FLAG_SHARED_ARENA | PW_FLAG_NO_STRIP);
+  if (!sub) return -1;
+  if (!sub->strips.empty()) { pw_batch_destroy(sub); return fail("internal: the replacement of a strip pair took the strips again"); }
+  if (pw_batch_share_arena(sub, b->d_arena) != 0 || pw_batch_solve(sub, nullptr) != 0) { pw_batch_destroy(sub); return -1; }
+  b->repaired.emplace_back(k, sub);
+  if (b->traced) { if (replay_trace(b, k, sub, nullptr) != 0) return -1; }
+  else HIP_TRY(hipMemcpyAsync(b->d_results + k, sub->d_results, sizeof(pw::Result), hipMemcpyDeviceToDevice, nullptr));
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  static const bool verbose = env_int("PWLIB_TIMING", 0) != 0;
+  if (verbose) fprintf(stderr, "pwlib: strip pipeline of pair %d abandoned; solved again on %s\n", (int)k, pw_batch_kernel_name(sub));
   return 0;
 }
 
@@ -844,6 +926,7 @@ static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
   }
   if (b->flags & PW_FLAG_PROFILE) HIP_TRY(hipEventRecord(b->ev_tr0, st));
   for (int32_t k : b->strips) {        // strip-layout pairs: one wavefront each (before the fix-up pass below)
+    if (repaired_sub(b, k)) continue;  // (its mask plane is that of an abandoned fill: the replacement walks its own)
     const pw::PairDesc& d = b->descs[k];
     pw::StripTraceParams sp;
     memset(&sp, 0, sizeof sp);
@@ -853,12 +936,14 @@ static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
     HIP_TRY(pw::launch_strip_trace(sp, st));
   }
   HIP_TRY(pw::launch_trace(p, st));
+  for (auto& r : b->repaired) if (replay_trace(b, r.first, r.second, st) != 0) return -1;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_tr1, st)); b->trace_timed = true; }
   return 0;
 }
 
 int pw_batch_traceback(pw_batch* b, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
+  b->traced = true; b->traced_from = false;
   return do_trace(b, nullptr, (hipStream_t)stream);
 }
 
@@ -879,6 +964,8 @@ int pw_batch_traceback_from(pw_batch* b, const int32_t* ends_ij, void* stream) {
     if (!ok) return fail("traceback end cell outside the table");
   }
   HIP_TRY(hipMemcpyAsync(b->d_ends, ends_ij, 8 * (size_t)b->n, hipMemcpyHostToDevice, st));
+  b->traced = true; b->traced_from = true;
+  b->last_ends.assign(ends_ij, ends_ij + 2 * (size_t)b->n);
   return do_trace(b, b->d_ends, st);
 }
 
@@ -902,9 +989,16 @@ int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap) 
 int pw_batch_results(pw_batch* b, pw_result* out) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->n) HIP_TRY(hipMemcpy(out, b->d_results, sizeof(pw_result) * (size_t)b->n, hipMemcpyDeviceToHost));
+  // (the D2H copy above has waited for everything launched on the default stream; callers that launched on another stream
+  //  synchronise it first, as for any read of the records)
   for (int32_t k : b->strips)
-    if ((out[k].status & PW_ST_BADPATH) && out[k].opt_i < 0)
-      return fail("the strip pipeline of a wide pair was abandoned (a wavefront waited too long for the strip above it)");
+    if ((out[k].status & PW_ST_BADPATH) && out[k].opt_i < 0 && !repaired_sub(b, k)) {
+      if (env_int("PWLIB_NO_STRIP_REPAIR", 0))
+        return fail("the strip pipeline of a wide pair was abandoned (a wavefront waited too long for the strip above it)");
+      if (repair_strip_pair(b, k) != 0)
+        return fail("the strip pipeline of a wide pair was abandoned and solving the pair again without it failed: " + std::string(g_err));
+      HIP_TRY(hipMemcpy(out + k, b->d_results + k, sizeof(pw_result), hipMemcpyDeviceToHost));
+    }
   return 0;
 }
 
@@ -925,7 +1019,7 @@ int pw_batch_scores(pw_batch* b, int32_t k, double* out, int64_t n) {
   } else {
     std::vector<int32_t> tmp((size_t)want);
     HIP_TRY(hipMemcpy(tmp.data(), (int32_t*)b->d_hdump + d.h_off, 4 * (size_t)want, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < want; i++) out[i] = (double)tmp[(size_t)i];
+    for (int64_t i = 0; i < want; i++) out[i] = (double)tmp[(size_t)i] * b->score_mul;
   }
   return 0;
 }
@@ -940,7 +1034,7 @@ int pw_batch_table(pw_batch* b, int32_t k, double* out, int64_t n) {
   double* dev = nullptr;
   HIP_TRY(hipMalloc((void**)&dev, 8 * (size_t)want));
   const void* plane = b->use_f64 ? (const void*)((double*)b->d_hdump + d.h_off) : (const void*)((int32_t*)b->d_hdump + d.h_off);
-  hipError_t e = pw::launch_table_rowmajor(plane, b->use_f64, d.X, d.Y, d.h_pitch, dev, nullptr);
+  hipError_t e = pw::launch_table_rowmajor(plane, b->use_f64, d.X, d.Y, d.h_pitch, b->score_mul, dev, nullptr);
   if (e == hipSuccess) e = hipMemcpy(out, dev, 8 * (size_t)want, hipMemcpyDeviceToHost);
   (void)hipFree(dev);
   if (e != hipSuccess) return fail(hipGetErrorString(e));

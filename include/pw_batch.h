@@ -65,6 +65,7 @@ typedef struct {
 #define PW_FLAG_FORCE_TILED 32   /* run every pair through the time-blocked tiled kernel (testing) */
 #define PW_FLAG_FORCE_STRIP 64   /* run every pair that the strip pipeline supports through it (testing) */
 #define PW_FLAG_SHARED_ARENA 128 /* the batch owns no arena: pw_batch_share_arena gives it a caller-owned device copy */
+#define PW_FLAG_NO_STRIP 256     /* never use the strip pipeline (K2c): wide pairs take the tiled / workgroup kernels */
 
 const char* pw_last_error(void);
 int pw_device_count(void);
@@ -124,7 +125,12 @@ void* pw_batch_results_device(pw_batch* b);            /* pw_result[n_pairs] */
 void* pw_batch_transcripts_device(pw_batch* b);        /* transcript slots, see pw_batch_tx_slot */
 uint64_t pw_batch_transcripts_bytes(const pw_batch* b);
 int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap); /* ops of pair k end at off+cap */
-int pw_batch_results(pw_batch* b, pw_result* host_out);                          /* synchronous D2H */
+/* Synchronous D2H.  A wide pair whose strip pipeline (K2c) gave up waiting (a starved or contended device; its record then
+ * carries PW_ST_BADPATH and no end cell) is solved again here, once, with the strips disabled, and every later traceback of
+ * the batch serves it from that replacement: callers of this function never see the abandoned state.  The *_async readers
+ * and pw_batch_results_device see the status bit only -- call pw_batch_results once to trigger the repair.  An error is
+ * returned only if the second solve fails as well. */
+int pw_batch_results(pw_batch* b, pw_result* host_out);
 int pw_batch_transcripts(pw_batch* b, uint8_t* host_out);                        /* synchronous D2H of all slots */
 /* score plane of pair k (PW_FLAG_DUMP_SCORES): out[(d-dmin)*pitch + a], pitch = min(X,Y)+1, as doubles */
 int pw_batch_scores(pw_batch* b, int32_t k, double* host_out, int64_t n);

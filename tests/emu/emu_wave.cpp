@@ -238,6 +238,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   a.hdump = hdump ? hd.data() : nullptr; a.results = &res; a.subst = sub.data();
   a.npairs = 1; a.L = L; a.brule = pl.brule; a.endrule = pl.endrule; a.banded = (mode == pw::BANDED_MODE);
   a.match = sub[0]; a.mismatch = L > 1 ? sub[1] : sub[0]; a.go = (T)go; a.ge = (T)ge;
+  a.score_mul = 1.0;
   const int generic = force_generic || !simple || go > 0 || hdump != nullptr;
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
@@ -310,6 +311,7 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
   a.epoch = epoch; a.brule = pl.brule; a.endrule = pl.endrule;
   a.match = (int32_t)match; a.mismatch = (int32_t)mismatch; a.go = (int32_t)go; a.ge = (int32_t)ge;
   a.spin_limit = 4;
+  a.score_mul = 1.0;
   const bool track = pl.endrule != pw::END_CORNER;
   for (int w = 0; w < a.nstrips; w++) {
     Emu emu;

@@ -1,0 +1,197 @@
+"""The scoring surface of the HIP path off the headline fast path (round 3): score sets that used to fall onto the f64 or
+the generic kernels -- dyadic-rational scores (exact scaling onto the integer kernels), small integer substitution
+matrices (packed 16-bit kernel with a matrix), START_ANCHORED / END_ANCHORED (their own packed instantiations) -- must
+report the fast kernels and stay bit-identical to the forced f64 / generic kernels and to the oracle.
+
+Reference semantics: biseqt/pwlib/_pw_internals.c:161-299 (move generators), :303-414 (end cells); the reference's
+arithmetic is IEEE double (pwlib.h:71-78, 141-152)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick')
+
+
+def _pairs(rng, n, lo, hi, L=4, unrelated_every=5):
+    from biseqt_amd import synth
+    pairs = []
+    for k in range(n):
+        X = int(rng.integers(lo, hi))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        if unrelated_every and k % unrelated_every == 0:
+            m = rng.integers(0, L, int(rng.integers(lo, hi))).astype(np.uint8)
+        elif k % 7 == 3 and X > 20:                        # a suffix of o is a prefix of m
+            m = np.concatenate([o[int(rng.integers(0, X)):], rng.integers(0, L, int(rng.integers(0, 60))).astype(np.uint8)])
+        else:
+            m = synth.mutate(rng, o, 0.06, 0.03, 0.4, L)
+        pairs.append((o, m))
+    return pairs
+
+
+def _run(pairs, flags=0, **kw):
+    from biseqt_amd.batch import BatchAligner
+    with BatchAligner(pairs, flags=flags, check_band=False, **kw) as b:
+        name, dtype = b.kernel_name, b.score_dtype
+        res = b.run().copy()
+        txs = b.transcripts(res)
+        rcs = [b.init_rc(k) for k in range(len(pairs))]
+    return name, dtype, res, txs, rcs
+
+
+def _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, every, where):
+    from biseqt_amd import _pwlib as W
+    for k in range(0, len(pairs), every):
+        r = oracle.solve(pairs[k][0], pairs[k][1], **okw)
+        w = (where, k)
+        assert rcs[k] == r['init_rc'], w
+        if r['init_rc'] != 0:
+            continue
+        assert (int(res['opt_i'][k]), int(res['opt_j'][k])) == tuple(r['opt']), w
+        if res['opt_i'][k] == -1:
+            continue
+        st = int(res['status'][k])
+        assert res['score'][k] == r['score'], (w, res['score'][k], r['score'])
+        assert bool(st & W.PW_ST_PANICK) == bool(r['would_panick']), w
+        if not (st & (W.PW_ST_PANICK | W.PW_ST_EMPTY)):
+            assert txs[k] == r['transcript'], w
+            assert (res['origin_idx'][k], res['mutant_idx'][k]) == (r['origin_idx'], r['mutant_idx']), w
+
+
+DYADIC_SETS = [(0.25, -1., 0., -1.),          # config 5's extension scores: match = 1 / p_min - 1 at p_min = 0.8 (pipeline.py)
+               (0.5, -1.5, -2.5, -1.),
+               (1.25, -0.75, -0.5, -0.25),
+               (2., -3.125, -4.5, -0.0625),
+               (0.001953125, -0.00390625, 0., -0.0009765625)]   # 2^-9 .. 2^-10: the deepest shift
+
+
+@pytest.mark.parametrize('mode,alntype,dr', [(1, 1, (-40, 35)), (1, 2, (-50, 50)), (1, 0, (-60, 60)), (0, 1, None),
+                                             (0, 0, None), (0, 4, None), (0, 2, None), (0, 3, None)],
+                         ids=['B_LOCAL', 'B_OVERLAP', 'B_GLOBAL', 'LOCAL', 'GLOBAL', 'OVERLAP', 'START_ANCHORED', 'END_ANCHORED'])
+def test_dyadic_scores_run_on_the_integer_kernels(oracle, mode, alntype, dr):
+    """Scores that are multiples of 2^-k are scaled by 2^k onto the integer kernels (exact: every partial sum of dyadic
+    rationals is exact in the reference's doubles): the batch must report an integer kernel, and its records and
+    transcripts must equal the forced f64 kernel's for every pair and the oracle's on a sample."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3100 + 10 * mode + alntype)
+    for si, (match, mismatch, go, ge) in enumerate(DYADIC_SETS):
+        pairs = _pairs(rng, 320, 0 if si == 1 else 20, 400 if mode else 200)
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=4, match_score=match, mismatch_score=mismatch,
+                  go_score=go, ge_score=ge)
+        if dr is not None:
+            kw['diag_range'] = dr
+        name, dtype, res, txs, rcs = _run(pairs, **kw)
+        name64, dtype64, res64, txs64, _ = _run(pairs, flags=W.PW_FLAG_FORCE_F64, **kw)
+        assert dtype == 'i32' and 'double' not in name, (name, kw)
+        assert dtype64 == 'f64' and 'double' in name64, name64
+        assert (res == res64).all() and txs == txs64, (name, kw)
+        okw = dict(L=4, mode=mode, alntype=alntype, diag_range=dr, match=match, mismatch=mismatch, go=go, ge=ge)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, 13, (name, kw))
+        if si == 0 and (mode, alntype) in ((1, 1), (1, 2), (1, 0), (0, 1), (0, 0), (0, 4)):
+            assert 'k_fill16' in name, name          # small scaled scores: the packed kernel
+
+
+def test_dyadic_substitution_matrix_and_positive_gap_open(oracle):
+    """Dyadic scaling also serves the generic path (a substitution matrix, go > 0): integer arithmetic, equal to f64."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3177)
+    subst = [[1.5, -0.5, -2.25, -0.5], [-0.5, 1.25, -0.5, -2.], [-2.25, -0.5, 1.75, -0.75], [-0.5, -2., -0.75, 1.]]
+    for mode, alntype, dr, go in ((1, 1, (-30, 30), -1.5), (0, 0, None, 0.75), (1, 2, (-45, 45), 0.25)):
+        pairs = _pairs(rng, 300, 10, 250)
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=4, subst_scores=subst, go_score=go, ge_score=-0.75)
+        if dr is not None:
+            kw['diag_range'] = dr
+        name, dtype, res, txs, rcs = _run(pairs, **kw)
+        name64, dtype64, res64, txs64, _ = _run(pairs, flags=W.PW_FLAG_FORCE_F64, **kw)
+        assert dtype == 'i32' and dtype64 == 'f64', (name, name64)
+        assert (res == res64).all() and txs == txs64, (name, kw)
+        okw = dict(L=4, mode=mode, alntype=alntype, diag_range=dr, subst=subst, go=go, ge=-0.75)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, 11, (name, kw))
+
+
+def test_non_dyadic_scores_stay_on_f64(oracle):
+    """0.1 is not a dyadic rational: such scores keep the f64 kernel (and PWLIB_NO_DYADIC=1 keeps dyadic ones there too)."""
+    import os
+    from biseqt_amd import synth
+    rng = synth.rng_for(3199)
+    pairs = _pairs(rng, 40, 20, 200)
+    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-30, 30), mismatch_score=-1., go_score=0., ge_score=-1.)
+    name, dtype, _, _, _ = _run(pairs, match_score=0.1, **kw)
+    assert dtype == 'f64', name
+    os.environ['PWLIB_NO_DYADIC'] = '1'
+    try:
+        name, dtype, res, txs, rcs = _run(pairs, match_score=0.25, **kw)
+    finally:
+        os.environ.pop('PWLIB_NO_DYADIC', None)
+    assert dtype == 'f64', name
+    name2, dtype2, res2, txs2, _ = _run(pairs, match_score=0.25, **kw)
+    assert dtype2 == 'i32' and (res == res2).all() and txs == txs2
+
+
+def test_dyadic_drop_in_table_scores(oracle):
+    """The drop-in's materialised table (Aligner.table_scores, pw.py:278-285) is scaled back too."""
+    from biseqt_amd import pw
+    from biseqt_amd.sequence import Alphabet
+    from biseqt_amd import synth
+    rng = synth.rng_for(3201)
+    A = Alphabet('ACGT')
+    o = rng.integers(0, 4, 60)
+    m = synth.mutate(rng, o.astype(np.uint8), 0.1, 0.05, 0.3)
+    S, T = A.parse(''.join('ACGT'[i] for i in o)), A.parse(''.join('ACGT'[i] for i in m))
+    with pw.Aligner(S, T, alntype=pw.LOCAL, match_score=0.75, mismatch_score=-1.25, go_score=-0.5, ge_score=-0.25) as a:
+        score = a.solve()
+        table = np.array(a.table_scores())
+        aln = a.traceback()
+    r = oracle.solve(o, m, L=4, mode=0, alntype=1, match=0.75, mismatch=-1.25, go=-0.5, ge=-0.25, want_table=True)
+    assert score == r['score'] and aln.transcript == r['transcript']
+    H = r['H'].reshape(len(o) + 1, len(m) + 1)
+    assert (table == H[:len(o), :len(m)]).all()
+
+
+def test_abandoned_strip_pipeline_is_solved_again(oracle, monkeypatch):
+    """A strip pipeline (K2c) whose waits run out of patience (PWLIB_STRIP_SPIN_LIMIT=1: the first poll that finds no granule
+    gives up) must drain, and `pw_batch_results` must solve the pair again without the strips: the caller sees the right
+    records and transcripts, never "no alignment".  A following solve with the default limit goes through the strips again.
+    PWLIB_NO_STRIP_REPAIR=1 surfaces the abandonment as an error instead."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    from biseqt_amd.batch import BatchAligner
+    rng = synth.rng_for(3301)
+    pairs = []
+    for n in (1500, 700, 2100):
+        o = synth.rand_seqs(rng, 1, n)[0]
+        pairs.append((o, synth.mutate(rng, o, 0.08, 0.04, 0.3)))
+    for alntype in (1, 0, 4):                               # LOCAL, GLOBAL, OVERLAP
+        kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2)
+        exp = [oracle.solve(o, m, L=4, mode=0, alntype=alntype, match=1, mismatch=-3, go=-5, ge=-2) for o, m in pairs]
+
+        def check(res, txs):
+            for k, r in enumerate(exp):
+                assert (int(res['opt_i'][k]), int(res['opt_j'][k])) == tuple(r['opt']), (alntype, k)
+                assert res['score'][k] == r['score'] and txs[k] == r['transcript'], (alntype, k)
+                assert not (int(res['status'][k]) & W.PW_ST_BADPATH)
+
+        with BatchAligner(pairs, flags=W.PW_FLAG_FORCE_STRIP, **kw) as b:
+            assert 'k_fill_strip' in b.kernel_name
+            monkeypatch.setenv('PWLIB_STRIP_SPIN_LIMIT', '1')
+            res = b.run()
+            check(res, b.transcripts(res))
+            # explicit end cells after a repair: served by the replacement too
+            b.traceback_from([(int(res['opt_i'][k]), int(res['opt_j'][k])) for k in range(len(pairs))])
+            b.sync()
+            res2 = b.results()
+            check(res2, b.transcripts(res2))
+            monkeypatch.delenv('PWLIB_STRIP_SPIN_LIMIT')
+            res3 = b.run()                                  # default patience: the strips again
+            check(res3, b.transcripts(res3))
+            monkeypatch.setenv('PWLIB_STRIP_SPIN_LIMIT', '1')
+            monkeypatch.setenv('PWLIB_NO_STRIP_REPAIR', '1')
+            b.solve(); b.traceback(); b.sync()
+            with pytest.raises(RuntimeError, match='abandoned'):
+                b.results()
+            monkeypatch.delenv('PWLIB_NO_STRIP_REPAIR')
+            monkeypatch.delenv('PWLIB_STRIP_SPIN_LIMIT')
+            res4 = b.run()
+            check(res4, b.transcripts(res4))
