@@ -25,11 +25,19 @@ Prints ONE JSON line (rank 0):
   serial                  the same steps with one batch in flight
   e2e_with_h2d_d2h        steps that also upload the sequences from pinned host memory and bring records and
                           transcripts back; never `value`
-  variants                the 32-bit kernel (the like-for-like width of the reference's integer results) and the
-                          linear-gap rerun (go 0) on the same pairs; config 1 through the four drop-in calls
+  variants                the 32-bit kernel (the like-for-like width of the reference's integer results), the f64 kernel
+                          (the reference's own arithmetic) and the linear-gap rerun (go 0) on the same pairs; config 1
+                          through the four drop-in calls
+  roofline.valu_*         VALU instructions of the dominant kernel from the committed rocprofv3 PMC passes
+                          (profiles/pmc_kernel.json), reported only while the built kernel's code fingerprint equals the
+                          one the counters were collected on (biseqt_amd/pwlib/kernel_hashes.json); null otherwise
   check                   what was verified about the batches the clock ran on
-  cpu_baseline            the reference pwlib itself (oracle/_ref) -- or the oracle restatement -- on the host cores,
-                          bounded sample of the same batch; its outputs are the `check.vs_reference` comparison
+  cpu_baseline            the reference pwlib itself (oracle/_ref, the reference's own -g flags) -- or the oracle
+                          restatement -- on the host cores, bounded sample of the same batch; its outputs are the
+                          `check.vs_reference` comparison.  cpu_baseline_O2: the same sources at -O2
+
+--min-seconds S (default 1): the timed region runs max(K, enough steps for S seconds) steps -- decided from the warm-up
+before the clock starts, `steps` reports what ran, `steps_requested` the K given; --min-seconds 0 times exactly K.
 """
 import argparse
 import json
@@ -48,6 +56,7 @@ import numpy as np  # noqa: E402
 PAIRS, LENGTH, RADIUS = 10000, 2000, 200
 SCORES = dict(match=1., mismatch=-3., go=-5., ge=-2.)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+N_SIMD, CLOCK_GHZ = 1024, 2.4   # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 CPU_SAMPLE_PER_CORE = 64
 
 
@@ -59,7 +68,8 @@ def batch_seed(rank, j):
 # CPU baseline (rank 0, N == 1): the reference library on the host cores, bounded sample of batch 0
 # ---------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
-    kind, first, origins, mutants, budget_s = args
+    kind, first, origins, mutants, budget_s = args[:5]
+    so_path = args[5] if len(args) > 5 else None
     sys.path.insert(0, ROOT)
     from biseqt_amd import synth
     cells = 0
@@ -67,7 +77,7 @@ def _cpu_worker(args):
     t0 = time.time()
     if kind == 'reference':
         from oracle import ref_driver as R
-        lib = R.load()
+        lib = R.load(so_path) if so_path else R.load()
         devnull = os.open(os.devnull, os.O_WRONLY)
         os.dup2(devnull, 1)           # the reference prints band messages to stdout
         for k in range(len(origins)):
@@ -89,10 +99,11 @@ def _cpu_worker(args):
     return cells, out, time.time() - t0
 
 
-def cpu_baseline(origins, mutants, budget_s=12.0):
+def cpu_baseline(origins, mutants, budget_s=12.0, so_name='pwlib_ref.so', flags='-g, no -O: the reference Makefile\'s own flags'):
     """Times the reference on the first pairs of the batch the GPU will run; returns (json object, reference answers)."""
     import multiprocessing as mp
-    kind = 'reference' if os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'pwlib_ref.so')) else 'port'
+    so_path = os.path.join(ROOT, 'oracle', '_ref', so_name)
+    kind = 'reference' if os.path.exists(so_path) else 'port'
     if kind == 'port':
         from oracle import oracle as O
         O.lib()
@@ -101,7 +112,7 @@ def cpu_baseline(origins, mutants, budget_s=12.0):
     ctx = mp.get_context('spawn')     # never fork a process that may touch the GPU
     t0 = time.time()
     with ctx.Pool(cores) as pool:
-        out = pool.map(_cpu_worker, [(kind, c * per, origins[c * per:(c + 1) * per], mutants[c * per:(c + 1) * per], budget_s)
+        out = pool.map(_cpu_worker, [(kind, c * per, origins[c * per:(c + 1) * per], mutants[c * per:(c + 1) * per], budget_s, so_path)
                                      for c in range(cores)])
     wall = time.time() - t0
     cells = sum(o[0] for o in out)
@@ -111,22 +122,29 @@ def cpu_baseline(origins, mutants, budget_s=12.0):
                sample='%d pairs of the timed cfg2 batch (2 kb x ~2 kb, band radius 200, B_LOCAL), %d single-threaded '
                       'processes, init+solve+traceback+free per pair, %.1f s busy / %.1f s wall'
                       % (len(answers), cores, busy, wall))
+    if kind == 'reference':
+        obj['build'] = 'oracle/_ref/%s (gcc %s)' % (so_name, flags)
     return obj, answers
 
 
-def pmc_traffic(kernel, pairs):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/pmc_traffic.json: WRITE_SIZE + 2 x FETCH_SIZE, KiB -> bytes, per MI355X_MICROARCH.md's gfx950
-    correction), valid only for the kernel and batch size they were collected on; else None."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+def pmc_counters(kernel, pairs):
+    """Counters of the dominant kernel from the committed rocprofv3 PMC passes (profiles/pmc_kernel.json), per launch:
+    HBM bytes (WRITE_SIZE + 2 x FETCH_SIZE, KiB -> bytes, per MI355X_MICROARCH.md's gfx950 correction) and VALU
+    instructions.  They describe ONE code object: the record carries the fingerprint of the kernel's instruction stream at
+    collection time, and it is used only while biseqt_amd/pwlib/kernel_hashes.json (written by the build) shows the same
+    fingerprint for the kernel that just ran, on the same batch size.  Returns (record or None, reason)."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_kernel.json')) as f:
             rec = json.load(f)
-        if rec.get('kernel') == kernel and rec.get('pairs') == pairs:
-            return rec['hbm_bytes_per_launch']
-    except (OSError, ValueError, KeyError):
-        pass
-    return None
+        with open(os.path.join(ROOT, 'biseqt_amd', 'pwlib', 'kernel_hashes.json')) as f:
+            built = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, 'no counter record or no kernel fingerprints (%s)' % e
+    if rec.get('kernel') != kernel or rec.get('pairs') != pairs:
+        return None, 'counters were collected on %s, %s pairs' % (rec.get('kernel'), rec.get('pairs'))
+    if built.get(rec.get('symbol')) != rec.get('code_sha256'):
+        return None, 'stale: the kernel was rebuilt with different code since the counters were collected'
+    return rec, 'profiles/pmc_kernel.json, code fingerprint %s' % rec['code_sha256'][:12]
 
 
 def _free_port():
@@ -160,6 +178,8 @@ def main():
     ap.add_argument('--inflight', type=int, default=2,
                     help='batches in flight per GPU, each on its own HIP stream (consecutive steps alternate); 2 hides the '
                          'latency-bound traceback of one batch behind the fill of the next')
+    ap.add_argument('--min-seconds', type=float, default=1.0,
+                    help='lower bound of the timed region: more than --steps steps are timed if needed (0: exactly --steps)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the serial / e2e / variant legs (profiling runs)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL gather path even with one rank (self-test)')
@@ -178,9 +198,13 @@ def main():
     nfl = max(1, args.inflight)
     seqs = [synth.pair_batch(batch_seed(rank, j), n_local, LENGTH) for j in range(nfl)]
 
-    cpu, ref_answers = None, []
+    cpu, cpu_o2, ref_answers = None, None, []
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, ref_answers = cpu_baseline(seqs[0][0], seqs[0][1])     # before anything touches the GPU
+        if cpu['kind'] == 'reference' and os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'pwlib_ref_O2.so')):
+            cpu_o2, o2_answers = cpu_baseline(seqs[0][0], seqs[0][1], budget_s=8.0, so_name='pwlib_ref_O2.so', flags='-O2')
+            same = {a[0]: a for a in ref_answers}
+            cpu_o2['answers_equal_the_g_build'] = all(same.get(a[0], a) == a for a in o2_answers)
 
     import torch
     import torch.distributed as dist
@@ -241,14 +265,27 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    # how many steps the timed region needs to last --min-seconds: measured on a few untimed steps, agreed over the ranks
+    steps_run = args.steps
+    if args.min_seconds > 0 and args.steps > 0:
+        np_ = max(2 * nfl, 4)
+        tp = time.perf_counter()
+        for i in range(np_):
+            step(i)
+        fence()
+        est = (time.perf_counter() - tp) / np_
+        need = torch.tensor([int(np.ceil(args.min_seconds / max(est, 1e-6)))], dtype=torch.int64, device=dev)
+        if use_dist:
+            dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        steps_run = max(args.steps, min(int(need.item()), 100000))
     done_cells = 0
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps_run):
         done_cells += step(i)
     fence()
     elapsed = time.perf_counter() - t0
     # fill-kernel duration of the LAST timed step of each batch: with two batches in flight the fills co-run
-    overlapped_ms = [b.fill_ms() for b in batches[:min(nfl, args.steps)]]
+    overlapped_ms = [b.fill_ms() for b in batches[:min(nfl, steps_run)]]
 
     t = torch.tensor([elapsed, float(done_cells)], dtype=torch.float64, device=dev)
     if use_dist:
@@ -288,7 +325,7 @@ def main():
         if rank == 0:
             # what arrived at the root: rank 0's own records bit for bit, and the last rank's records + transcripts,
             # regenerated here from its seed and re-scored
-            last_j = (args.steps - 1) % nfl if args.steps else 0
+            last_j = (steps_run - 1) % nfl if steps_run else 0
             got0 = gathered[last_j][0].cpu().numpy().view(RESULT_DTYPE)
             gather_ok = bool((got0 == results[last_j]).all())
             r_last = world - 1
@@ -371,6 +408,7 @@ def main():
             b.close()
         # (3) the same pairs through the 32-bit kernel, and with linear gaps (go 0), each checked by re-scoring
         for name, flags, go in (('int32_kernel', W.PW_FLAG_NO_PACKED16 | W.PW_FLAG_PROFILE, SCORES['go']),
+                                ('f64_kernel', W.PW_FLAG_FORCE_F64 | W.PW_FLAG_PROFILE, SCORES['go']),
                                 ('linear_gap_go0', W.PW_FLAG_PROFILE, 0.0)):
             kw2 = dict(akw); kw2['go_score'] = go
             with BatchAligner(list(zip(*seqs[0])), flags=flags, **kw2) as b2:
@@ -417,11 +455,14 @@ def main():
 
     if rank == 0:
         value = total_done / elapsed / 1e9          # cells of every step of every rank / max-over-ranks time
-        ms_step = elapsed / args.steps * 1e3
+        ms_step = elapsed / steps_run * 1e3
         achieved = alg_bytes / (fill * 1e-3) / 1e9
+        pmc, pmc_src = pmc_counters(batch.kernel_name, n_local)
+        valu = pmc.get('SQ_INSTS_VALU') if pmc else None
         line = {
             'metric': 'GCUPS (DP cell updates/s) banded local align',
-            'value': round(value, 3), 'unit': 'GCUPS', 'n_gpus': world, 'steps': args.steps,
+            'value': round(value, 3), 'unit': 'GCUPS', 'n_gpus': world, 'steps': steps_run, 'steps_requested': args.steps,
+            'timed_region_s': round(elapsed, 4),
             'warmup': args.warmup, 'ms_per_step': round(ms_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             # the arithmetic the dominant kernel computes in: packed 16-bit lanes for k_fill16, else i32 / f64
@@ -435,7 +476,15 @@ def main():
                        'pairs_per_gpu': n_local, 'cells_per_gpu': int(cells), 'batches_in_flight': nfl,
                        'parallelism': 'pairs round-robin x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc_traffic(batch.kernel_name, n_local),
+                         'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': pmc['hbm_bytes_per_launch'] if pmc else None,
+                         'counters_source': pmc_src,
+                         # VALU wave-instructions per launch x 4 issue cycles over the SIMD-cycles of the live launch
+                         # duration at the peak clock: how busy the vector ALUs are (the kernel's real bound)
+                         'valu_busy_frac': round(valu * 4 / (N_SIMD * fill * 1e-3 * CLOCK_GHZ * 1e9), 4) if valu else None,
+                         # lane-level VALU instructions per DP cell (wave-instructions x 64 lanes / cells; a packed
+                         # instruction updates two cells, idle lanes included)
+                         'valu_insts_per_cell': round(valu * 64 / cells, 3) if valu else None,
+                         'valu_wave_insts_per_launch': valu,
                          'kernel': batch.kernel_name,
                          'kernel_ms': round(fill, 4),
                          'kernel_ms_note': 'HIP events on the launch stream, mean of %d launches of one batch running alone '
@@ -451,6 +500,8 @@ def main():
         if variants:
             line['variants'] = variants
         line['cpu_baseline'] = cpu          # timed at N = 1 only (null otherwise, or with --no-cpu-baseline)
+        if cpu_o2 is not None:
+            line['cpu_baseline_O2'] = cpu_o2
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + '\n').encode())
     for b in batches:

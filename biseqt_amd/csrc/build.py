@@ -25,17 +25,21 @@ COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-ffp-contract
           '-Wno-unused-function'] + os.environ.get('PW_EXTRA_CXXFLAGS', '').split()
 BKS = (2, 4, 8, 16, 32)
 PACKED_BKS = (4, 8, 12, 16, 20, 24, 28, 32)
-# Wavefronts per SIMD the packed kernels are held to, (bk, rule) -> (one pair per wavefront, lane-packed); absent / 0 =
+PACKED_RULES = (0, 1, 2, 3, 4, 5)      # pw_wave.h, WaveFill16: local, overlap, global, local x4, END_ANCHORED, START_ANCHORED
+PACKED_MAT_RULES = (0, 1, 2, 3)        # ... with a substitution matrix of up to 4 x 4 letters
+# Wavefronts per SIMD the packed kernels are held to, (bk, rule, matrix) -> (one pair per wavefront, lane-packed); absent / 0 =
 # the compiler's default.  The max-ilp schedule spends registers freely; a bound makes it fit fewer.  Only the entries
 # measured faster are listed (tests/micro/ab_occupancy.sh): BK = 8 local rules 157 -> 87 VGPRs, config 2 fill 1-2 % and
 # the pipelined step 3 % faster; BK = 16 local rules 177 -> 165 VGPRs, 2.8 % on an 801-diagonal band.  Every other
 # instantiation compiled without a spill at one more wavefront per SIMD too, and ran the same within 2 % -- or slower: the
 # lane-packed BK = 4 body at 4 per SIMD (169 -> 109 VGPRs) lost 24-35 % on 20 000 pairs with a 21-diagonal band.
-FILL16_WAVES = {
-    (8, 0): (5, 0), (8, 3): (5, 0),
-    (16, 0): (3, 0), (16, 3): (3, 0),
+FILL16_WAVES = {      # (bk, rule, matrix)
+    (8, 0, 0): (5, 0), (8, 3, 0): (5, 0),
+    (16, 0, 0): (3, 0), (16, 3, 0): (3, 0),
 }
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
+# objects whose kernels get a fingerprint in biseqt_amd/pwlib/kernel_hashes.json (config 2's and config 3's fill kernels)
+HASHED_OBJECTS = ('pw_fill16_bk8_r3.o', 'pw_fill16_bk8_r0.o', 'pw_fill_i32_bk8.o', 'pw_fill_f64_bk8.o', 'pw_strip.o')
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
 
 
@@ -55,12 +59,12 @@ def _jobs():
         obj = os.path.join(OBJ_DIR, 'pw_fill_tile_%s.o' % tn)
         cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_tile_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tile_tu.hip')]))
-    for bk, rule in [(bk, 0) for bk in PACKED_BKS] + [(bk, r) for r in (1, 2) for bk in PACKED_BKS] + [(bk, 3) for bk in PACKED_BKS]:
-        obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d_r%d.o' % (bk, rule))
+    for bk, rule, mat in [(bk, r, 0) for r in PACKED_RULES for bk in PACKED_BKS] + [(bk, r, 1) for r in PACKED_MAT_RULES for bk in PACKED_BKS]:
+        obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d_r%d%s.o' % (bk, rule, '_mat' if mat else ''))
         # max-ilp scheduling: dependent VOP3P ops need a wait state between them; the default (occupancy first)
         # schedule leaves ~15% of the issue slots of the packed kernel to s_nop, this one none (measured)
-        occ, occ_seg = FILL16_WAVES.get((bk, rule), (0, 0)) if os.environ.get('PW_FILL16_OCCUPANCY', '1') != '0' else (0, 0)
-        cmd = [HIPCC] + COMMON + ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-DPW_BK=%d' % bk, '-DPW_RULE=%d' % rule,
+        occ, occ_seg = FILL16_WAVES.get((bk, rule, mat), (0, 0)) if os.environ.get('PW_FILL16_OCCUPANCY', '1') != '0' else (0, 0)
+        cmd = [HIPCC] + COMMON + ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-DPW_BK=%d' % bk, '-DPW_RULE=%d' % rule, '-DPW_MAT=%d' % mat,
                                   '-DPW_FILL16_WAVES=%d' % occ, '-DPW_FILL16_WAVES_SEG=%d' % occ_seg, '-c',
                os.path.join(HERE, 'pw_fill16_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill16_tu.hip')]))
@@ -150,6 +154,17 @@ def build(force=False, verbose=True):
         if verbose:
             print('[build] linked', SO)
     shutil.copyfile(os.path.join(ROOT, 'include', 'pwlib.h'), os.path.join(OUT_DIR, 'pwlib.h'))
+    hashes = os.path.join(OUT_DIR, 'kernel_hashes.json')
+    if force or todo or not os.path.exists(hashes):
+        # Fingerprints of the kernels whose rocprofv3 counters are quoted from committed files (profiles/pmc_kernel.json):
+        # bench.py reports those counters only while the kernel it runs still has the code they were collected on.
+        from . import codeobj
+        import json
+        fp = {}
+        for obj in HASHED_OBJECTS:
+            fp.update(codeobj.kernel_fingerprints(os.path.join(OBJ_DIR, obj)))
+        with open(hashes, 'w') as f:
+            json.dump(fp, f, indent=1, sort_keys=True)
     return SO
 
 

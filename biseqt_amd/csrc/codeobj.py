@@ -80,6 +80,25 @@ def disassembly(obj_path, symbol_substr=None):
     return funcs
 
 
+def kernel_fingerprints(obj_path):
+    """{demangled kernel name: sha256 of its instruction stream} for every kernel of the object.  Addresses are left out
+    (another kernel of the same object growing must not change the print); branch targets stay as symbol-relative text."""
+    import hashlib
+    md = kernel_metadata(obj_path)
+    by_symbol = {k['name']: n for n, k in md.items()}
+    out = {}
+    for sym, lines in disassembly(obj_path, '').items():
+        if sym not in by_symbol:
+            continue
+        h = hashlib.sha256()
+        for ln in lines:
+            ins = re.sub(r'\s+', ' ', ln.split('//')[0]).strip()
+            ins = re.sub(r'^[0-9a-f]+:\s*', '', ins)
+            h.update(ins.encode() + b'\n')
+        out[by_symbol[sym]] = h.hexdigest()
+    return out
+
+
 # ---- the invariants of the hand-scheduled strip kernel (pw_strip.hip, DevPS::fifo_load_async / wait_vm) --------------
 # The FIFO hand-over loads land in accumulation registers a0..a3 through asm statements the compiler does not track.
 # That is sound only while the compiler itself never allocates AGPRs in k_fill_strip (no AGPR spills of VGPRs, no MFMA):

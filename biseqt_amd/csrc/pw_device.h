@@ -166,22 +166,22 @@ template <int BK, bool SEG, int RULE> struct Fill16Occupancy {
   static constexpr unsigned w = SEG ? PW_FILL16_WAVES_SEG : PW_FILL16_WAVES;
   static constexpr unsigned lo = w ? w : 1, hi = w ? w : 8;
 };
-template <int BK, bool SEG, int RULE>
+template <int BK, bool SEG, int RULE, bool MAT = false>
 __global__ __launch_bounds__(64) PW_FILL_ATTR
 __attribute__((amdgpu_waves_per_eu(Fill16Occupancy<BK, SEG, RULE>::lo, Fill16Occupancy<BK, SEG, RULE>::hi)))
 void k_fill16(const FillParams<int32_t> a) {
   const WaveDesc wd = a.waves[blockIdx.x];
-  WaveFill16<DevP, BK, SEG, RULE> w(a, wd);
+  WaveFill16<DevP, BK, SEG, RULE, MAT> w(a, wd);
   w.run();
 }
 
 // The same 16-bit body on a workgroup of up to 8 wavefronts per pair (K2a's exchange through LDS): bands of 2049 .. 16 384
 // diagonals, e.g. standard-mode tables of 1 .. 8 kb, whose scores fit the packed kernel.  One WaveDesc per pair,
 // nl = 64 x wavefronts.
-template <int BK, int RULE>
+template <int BK, int RULE, bool MAT = false>
 __global__ __launch_bounds__(512) void k_fill16_mw(const FillParams<int32_t> a) {
   const WaveDesc wd = a.waves[blockIdx.x];
-  WaveFill16<DevPM, BK, false, RULE> w(a, wd);
+  WaveFill16<DevPM, BK, false, RULE, MAT> w(a, wd);
   w.run();
 }
 

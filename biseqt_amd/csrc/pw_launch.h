@@ -24,8 +24,9 @@ hipError_t launch_fill(const FillParams<double>& a, int variant, int bk, int nbl
 static const int kPackedBK[] = {4, 8, 12, 16, 20, 24, 28, 32};
 static const int kNumPackedBK = 8;
 // seg != 0: several pairs per wavefront (WaveDesc.nl lanes each); seg == 0: one pair per wavefront, WaveDesc.nl == 64
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int nwaves, hipStream_t st);
-hipError_t launch_fill16_mw(const FillParams<int32_t>& a, int bk, int rule, int nw, int npairs, hipStream_t st);   // nw wavefronts per pair
+// rule: 0 .. 5 (pw_wave.h, WaveFill16); mat != 0: scores from FillParams::mat_rows (rules 0 .. 3 only)
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int mat, int nwaves, hipStream_t st);
+hipError_t launch_fill16_mw(const FillParams<int32_t>& a, int bk, int rule, int mat, int nw, int npairs, hipStream_t st);   // nw wavefronts per pair
 // wide bands: one workgroup of nw wavefronts (2048 diagonals each, nw <= kMaxWavesPerPair) per pair
 static const int kMaxWavesPerPair = 8;
 hipError_t launch_fill_mw(const FillParams<int32_t>& a, int variant, int bk, int nw, int nblocks, hipStream_t st);

@@ -115,12 +115,14 @@ hipError_t launch_trace(const TraceParams& p, hipStream_t st) {
 PW_DECL(i32, int32_t)
 PW_DECL(f64, double)
 #undef PW_DECL
-#define PW_DECL16(BK, R) hipError_t launch_fill16_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t); \
-  hipError_t launch_fill16mw_bk##BK##_r##R(const FillParams<int32_t>&, int, int, hipStream_t);
-PW_DECL16(4, 0) PW_DECL16(8, 0) PW_DECL16(12, 0) PW_DECL16(16, 0) PW_DECL16(20, 0) PW_DECL16(24, 0) PW_DECL16(28, 0) PW_DECL16(32, 0)
-PW_DECL16(4, 1) PW_DECL16(8, 1) PW_DECL16(12, 1) PW_DECL16(16, 1) PW_DECL16(20, 1) PW_DECL16(24, 1) PW_DECL16(28, 1) PW_DECL16(32, 1)
-PW_DECL16(4, 2) PW_DECL16(8, 2) PW_DECL16(12, 2) PW_DECL16(16, 2) PW_DECL16(20, 2) PW_DECL16(24, 2) PW_DECL16(28, 2) PW_DECL16(32, 2)
-PW_DECL16(4, 3) PW_DECL16(8, 3) PW_DECL16(12, 3) PW_DECL16(16, 3) PW_DECL16(20, 3) PW_DECL16(24, 3) PW_DECL16(28, 3) PW_DECL16(32, 3)
+// the packed kernels: one launcher pair per (diagonals per lane, rule, matrix) translation unit (pw_fill16_tu.hip);
+// rules 0 .. 5 without a matrix, rules 0 .. 3 with one
+#define PW_BKS(M, R, MT) M(4, R, MT) M(8, R, MT) M(12, R, MT) M(16, R, MT) M(20, R, MT) M(24, R, MT) M(28, R, MT) M(32, R, MT)
+#define PW_ALL16(M) PW_BKS(M, 0, 0) PW_BKS(M, 1, 0) PW_BKS(M, 2, 0) PW_BKS(M, 3, 0) PW_BKS(M, 4, 0) PW_BKS(M, 5, 0) \
+                    PW_BKS(M, 0, 1) PW_BKS(M, 1, 1) PW_BKS(M, 2, 1) PW_BKS(M, 3, 1)
+#define PW_DECL16(BK, R, MT) hipError_t launch_fill16_bk##BK##_r##R##_m##MT(const FillParams<int32_t>&, int, int, hipStream_t); \
+  hipError_t launch_fill16mw_bk##BK##_r##R##_m##MT(const FillParams<int32_t>&, int, int, hipStream_t);
+PW_ALL16(PW_DECL16)
 #undef PW_DECL16
 
 hipError_t launch_tile_i32(const FillParams<int32_t>&, int, int, int, hipStream_t);
@@ -141,25 +143,19 @@ hipError_t launch_fill_mw(const FillParams<double>& a, int variant, int bk, int 
   return launch_fill_mw_f64(a, variant, bk, nw, nblocks, st);
 }
 
-hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int nwaves, hipStream_t st) {
-#define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16_bk##BK##_r##R(a, seg, nwaves, st);
-  switch (bk * 4 + rule) {
-    PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
-    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1) PW_CASE16(24, 1) PW_CASE16(28, 1) PW_CASE16(32, 1)
-    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2) PW_CASE16(24, 2) PW_CASE16(28, 2) PW_CASE16(32, 2)
-    PW_CASE16(4, 3) PW_CASE16(8, 3) PW_CASE16(12, 3) PW_CASE16(16, 3) PW_CASE16(20, 3) PW_CASE16(24, 3) PW_CASE16(28, 3) PW_CASE16(32, 3)
+hipError_t launch_fill16(const FillParams<int32_t>& a, int bk, int seg, int rule, int mat, int nwaves, hipStream_t st) {
+#define PW_CASE16(BK, R, MT) case ((BK) * 8 + (R)) * 2 + (MT): return launch_fill16_bk##BK##_r##R##_m##MT(a, seg, nwaves, st);
+  switch ((bk * 8 + rule) * 2 + (mat ? 1 : 0)) {
+    PW_ALL16(PW_CASE16)
     default: return hipErrorInvalidValue;
   }
 #undef PW_CASE16
 }
 
-hipError_t launch_fill16_mw(const FillParams<int32_t>& a, int bk, int rule, int nw, int npairs, hipStream_t st) {
-#define PW_CASE16(BK, R) case (BK) * 4 + (R): return launch_fill16mw_bk##BK##_r##R(a, nw, npairs, st);
-  switch (bk * 4 + rule) {
-    PW_CASE16(4, 0) PW_CASE16(8, 0) PW_CASE16(12, 0) PW_CASE16(16, 0) PW_CASE16(20, 0) PW_CASE16(24, 0) PW_CASE16(28, 0) PW_CASE16(32, 0)
-    PW_CASE16(4, 1) PW_CASE16(8, 1) PW_CASE16(12, 1) PW_CASE16(16, 1) PW_CASE16(20, 1) PW_CASE16(24, 1) PW_CASE16(28, 1) PW_CASE16(32, 1)
-    PW_CASE16(4, 2) PW_CASE16(8, 2) PW_CASE16(12, 2) PW_CASE16(16, 2) PW_CASE16(20, 2) PW_CASE16(24, 2) PW_CASE16(28, 2) PW_CASE16(32, 2)
-    PW_CASE16(4, 3) PW_CASE16(8, 3) PW_CASE16(12, 3) PW_CASE16(16, 3) PW_CASE16(20, 3) PW_CASE16(24, 3) PW_CASE16(28, 3) PW_CASE16(32, 3)
+hipError_t launch_fill16_mw(const FillParams<int32_t>& a, int bk, int rule, int mat, int nw, int npairs, hipStream_t st) {
+#define PW_CASE16(BK, R, MT) case ((BK) * 8 + (R)) * 2 + (MT): return launch_fill16mw_bk##BK##_r##R##_m##MT(a, nw, npairs, st);
+  switch ((bk * 8 + rule) * 2 + (mat ? 1 : 0)) {
+    PW_ALL16(PW_CASE16)
     default: return hipErrorInvalidValue;
   }
 #undef PW_CASE16

@@ -109,6 +109,10 @@ struct FillParams {
   // Dyadic scaling (host planner): scores that are multiples of 2^-k are held times 2^k by the integer kernels; the
   // reported score is the kernel's value times score_mul = 2^-k (exact).  1.0 otherwise.
   double score_mul;
+  // Packed kernels with a substitution matrix (WaveFill16<.., MAT = true>; alphabets of up to 4 letters): row o holds the
+  // four bytes scale * (subst[o][m] - min(subst)), m = 0 .. 3 from the low byte up; mat_bias = scale * -min(subst)
+  uint32_t mat_rows[4];
+  int32_t mat_bias;
 };
 
 struct TraceParams {

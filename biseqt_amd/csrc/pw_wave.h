@@ -582,6 +582,9 @@ PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return __builtin_amdgcn_align
 // sign mask per half (0xffff where negative): arithmetic shift by sh15 = (15, 15) held in an opaque register
 PW_FN uint32_t sign(uint32_t a, uint32_t sh15) { return __builtin_bit_cast(uint32_t, (s2_t)(as_s2(a) >> as_s2(sh15))); }
 PW_FN uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+// v_perm_b32: byte i of the result is byte sel[i] of the 8 bytes {a (4 .. 7), b (0 .. 3)}; selector 8 .. 11 = the sign of
+// byte 1 / 3 / 5 / 7 spread over the byte, 12 = 0x00, 13 and up = 0xff
+PW_FN uint32_t perm(uint32_t a, uint32_t b, uint32_t sel) { return __builtin_amdgcn_perm(a, b, sel); }
 #else
 PW_FN uint32_t mk(uint32_t lo, uint32_t hi) { return (lo & 0xffffu) | (hi << 16); }
 PW_FN int32_t sl(uint32_t v) { return (int16_t)(v & 0xffffu); }
@@ -605,6 +608,20 @@ PW_FN uint32_t mins(uint32_t a, uint32_t b) { return mk((uint32_t)(sl(a) < sl(b)
 PW_FN uint32_t align16(uint32_t hi, uint32_t lo) { return (lo >> 16) | (hi << 16); }
 PW_FN uint32_t sign(uint32_t a, uint32_t) { return mk(sl(a) < 0 ? 0xffffu : 0u, sh(a) < 0 ? 0xffffu : 0u); }
 PW_FN uint32_t opaque(uint32_t v) { return v; }
+PW_FN uint32_t perm(uint32_t a, uint32_t b, uint32_t sel) {
+  const uint64_t in = ((uint64_t)a << 32) | b;
+  uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t c = (sel >> (8 * i)) & 0xffu;
+    uint32_t v;
+    if (c >= 13) v = 0xffu;
+    else if (c == 12) v = 0u;
+    else if (c >= 8) v = ((in >> (8 * (2 * (c - 8) + 1) + 7)) & 1u) ? 0xffu : 0u;
+    else v = (uint32_t)(in >> (8 * c)) & 0xffu;
+    r |= v << (8 * i);
+  }
+  return r;
+}
 #endif
 PW_FN uint32_t both(int32_t v) { return ((uint32_t)v & 0xffffu) | ((uint32_t)v << 16); }
 PW_FN uint32_t pack(int32_t lo, int32_t hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
@@ -621,7 +638,18 @@ PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 // see the host planner), the first diagonal above the band is silenced by clamping its offer (adding a second sentinel to a
 // real score could wrap), every cell takes max(.., sentinel) -- which also pins cells before a diagonal's start and
 // beyond its end -- and instead of tracking a best the value of each diagonal's last cell is captured.
-template <class P, int BK, bool SEG, int RULE = 0>
+//   4  END_ANCHORED (standard)   begin anywhere like rule 0 (scores >= 0, shallow sentinel), end = cell (X, Y): the last
+//                                 cell of diagonal X - Y is captured, nothing is tracked
+//   5  START_ANCHORED (standard) begin at (0, 0) only like rule 2 (negative scores, deep sentinel), end = the first best
+//                                 cell anywhere, which must beat 0 (_pw_internals.c:342): the running best is tracked as a
+//                                 key over max(H, 0), so real scores must stay within [-23000, 8000]
+// MAT: the diagonal candidate takes its score from an integer substitution matrix of up to 4 x 4 letters instead of
+// match / mismatch (_alnchoice_M, _pw_internals.c:217-245: subst_scores[o][m]).  The origin window then carries, per
+// cell, the origin letter's ROW of the matrix -- four bytes subst[o][.] - min(subst) (times 4 under rule 3), at most 127
+// each -- and the mutant window carries byte SELECTORS (0x0c00 | letter, + 4 in the high half of a register): one
+// v_perm_b32 looks up both cells of a pair.  Letters outside a sequence are the all-zero row / a selector that reads as
+// 0x00: the matrix minimum, which the planner requires to be <= 0 ("matches nothing").
+template <class P, int BK, bool SEG, int RULE = 0, bool MAT = false>
 struct WaveFill16 {
   // RULE 3 = rule 0 with every score held times 4 (admitted when the scores stay below 2048): a kept-or-not difference
   // of two running values is then 0 or at least 4, so min(x, 2) and min(x, 4) deliver the D and I tie bits already
@@ -629,12 +657,19 @@ struct WaveFill16 {
   static constexpr bool SC4 = RULE == 3;
   static constexpr int RL = SC4 ? 0 : RULE;
   static constexpr int SCL = SC4 ? 4 : 1;
+  // what the rules are made of
+  static constexpr bool ANYB = RL == 0 || RL == 4;   // an alignment may begin in every cell: scores >= 0, sentinel -8192
+  static constexpr bool TRK = RL == 0 || RL == 5;    // the first best cell of every diagonal is tracked (as a key)
+  static constexpr bool CAP = !TRK;                  // the value of every diagonal's last cell is captured instead
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
   static constexpr int UNR = BK <= 8 ? 4 : (BK <= 16 ? 2 : 1);   // iterations unrolled per loop trip
-  static constexpr int32_t NEG16 = RL == 0 ? -8192 : -24000;
+  static constexpr int32_t NEG16 = ANYB ? -8192 : -24000;
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
+  // MAT: selector codes of a mutant letter in the low / high half of a register; outside the sequence 8 / 12, which both
+  // read as 0x00 (8 = the sign of a row byte, and row bytes stay below 128)
+  static constexpr uint32_t MSEL = 0x0c00u, MSENT_LO = 0x0c08u, MSENT_HI = 0x0c0cu;
   using Base = WaveFill<P, int32_t, BK, true, true, false>;       // only its static feeder helpers are used
 
   // SEG = true, lane packing: a wavefront holds `count` pairs side by side, `nl` lanes each (WaveDesc).
@@ -662,6 +697,8 @@ struct WaveFill16 {
   uint32_t tfE[RH], tfO[RH], tlE[RH], tlO[RH];          // first / last step of each diagonal
   uint32_t accE[RH], accO[RH], acc2E[RH], acc2O[RH];    // inverted tie nibbles: cells 0-3 / 4-7 of a block
   uint32_t OW[RH], MW[RH];
+  uint32_t ROW[MAT ? R : 1];                            // MAT: the matrix row of every cell's origin letter
+  uint32_t BIASV, MADJ;                                 // MAT: -min(subst) in both halves; the selector fix-up of the mutant window
   uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, GOVI, NEGV, LIMV;
   // RULE 0, steady blocks: the running best of a slot as a key 8 H + (7 - cell within the block) -- one multiply-add and
   // one unsigned maximum per cell pair instead of maximum, compare, subtract and multiply-add (H <= 8191: the planner
@@ -693,13 +730,19 @@ struct WaveFill16 {
   template <int EK>
   PW_FN void cellpair(uint32_t& Hs, uint32_t& Us, uint32_t& Ls, uint32_t& bests, uint32_t& bts, uint32_t geb,
                       uint32_t tf, uint32_t tl, uint32_t& acc, uint32_t up, uint32_t left, uint32_t oc,
-                      uint32_t mc, uint32_t tv, uint32_t clampL = 0) {
+                      uint32_t mc, uint32_t tv, uint32_t clampL = 0, uint32_t och = 0) {
     constexpr bool EDGE = EK != 0;
-    const uint32_t ne = pk::minu(oc ^ mc, ONE);                 // 0 where the letters match
-    const uint32_t hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
+    uint32_t hM;
+    if (MAT) {
+      // oc / och: the matrix rows of the low / high cell's origin letter, mc: the two selectors
+      hM = pk::sub(pk::add(Hs, pk::perm(och, oc, mc)), BIASV);
+    } else {
+      const uint32_t ne = pk::minu(oc ^ mc, ONE);               // 0 where the letters match
+      hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
+    }
     uint32_t Hn = pk::max(pk::max(up, left), hM);
     uint32_t nB;
-    if (RL == 0) {
+    if (ANYB) {
       if (EK & 1) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
       else Hn = pk::max(Hn, 0u);                                 // B: an alignment may begin anywhere, score 0
       nB = pk::minu(Hn, ONE);
@@ -715,13 +758,13 @@ struct WaveFill16 {
     const uint32_t hg = pk::add(Hn, geb);
     Us = pk::mad(nD, GOV, hg);                                   // (H + ge) + go unless a D choice is kept
     Ls = pk::mad(nI, GOVI, hg);
-    if (RL != 0) Ls = pk::mins(Ls, clampL);
+    if (!ANYB) Ls = pk::mins(Ls, clampL);
     // nibble = nB + 2 nD + 4 nI, appended to the accumulator: three packed multiply-adds
     if (SC4) acc = pk::mad(acc, C16, nB + nD + nI);             // (halves below 8: a plain 32-bit three-operand add)
     else acc = pk::mad(acc, C16, pk::mad(nI, C4, pk::mad(nD, C2, nB)));
-    if (RL == 0) {
+    if (TRK) {
       // (the running best is kept as a key by iteration16)
-    } else if (EDGE) {
+    } else if (EK & 2) {
       const uint32_t e = pk::minu(tv ^ tl, ONE);                 // 0 in the diagonal's last cell
       bests = pk::mad(e, pk::sub(bests, Hn), Hn);                // e ? bests : Hn
     }
@@ -741,7 +784,7 @@ struct WaveFill16 {
   // count as 0, cells beyond a diagonal's end are masked out -- neither can beat 8 best + 7.
   template <int EK>
   PW_FN void track_key(uint32_t& kb, uint32_t H, uint32_t tl, uint32_t tv, int k) {
-    const uint32_t hk = (EK & 1) ? pk::max(H, 0u) : H;
+    const uint32_t hk = (!ANYB || (EK & 1)) ? pk::max(H, 0u) : H;   // (rule 5: real scores go negative and count as 0)
     uint32_t key = pk::mad(hk, SC4 ? C2 : C8, pk::both(7 - k));
     if (EK & 2) key &= ~pk::sign(pk::sub(tl, tv), SH15);
     kb = pk::maxu(kb, key);
@@ -761,8 +804,9 @@ struct WaveFill16 {
       for (int p = 0; p < RH; p++)
       {
         cellpair<EK>(HE[p], UE[p], LE[p], bestE[p], btE[p], gebE[p], tfE[p], tlE[p], HALF == 0 ? accE[p] : acc2E[p],
-                     p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], OW[p], MW[p], tv0, clE[p]);
-        if (RL == 0) track_key<EK>(kbE[p], HE[p], tlE[p], tv0, k);
+                     p == 0 ? up0 : UO[p == 0 ? 0 : p - 1], LO[p], MAT ? ROW[MAT ? p : 0] : OW[p], MW[p], tv0, clE[p],
+                     MAT ? ROW[MAT ? p + RH : 0] : 0u);
+        if (TRK) track_key<EK>(kbE[p], HE[p], tlE[p], tv0, k);
       }
     }
     // origin window moves on: last register <- (own first.hi, next lane's first.lo | the pair's feeder).
@@ -774,17 +818,25 @@ struct WaveFill16 {
     {
       const int oi = xfeed_o + it;
       const uint32_t fb = Base::feed_byte(fo_lo, fo_hi, k);
-      const uint32_t feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? fb : SENT_O;
-      int32_t mv[2] = {(int32_t)OW[0], (int32_t)LE[0]};
+      uint32_t feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? fb : SENT_O;
+      if (MAT) feed = (!EDGE || (uint32_t)oi < (uint32_t)X) ? row_of(fb) : 0u;
+      int32_t mv[2] = {(int32_t)(MAT ? ROW[0] : OW[0]), (int32_t)LE[0]};
       const int32_t mo[2] = {(int32_t)feed, (int32_t)NEGV};
       xshlv<P, 2>(mv, mo, phase_l); phase_l ^= 1;
       uint32_t nxt = (uint32_t)mv[0];
       nxt_left = (uint32_t)mv[1];
       if (SEG) nxt = seglast ? feed : nxt;
-      const uint32_t last = pk::align16(nxt, OW[0]);
+      if (MAT) {
+        // whole registers: the window of rows moves on by renaming
 #pragma unroll
-      for (int p = 0; p + 1 < RH; p++) OW[p] = OW[p + 1];
-      OW[RH - 1] = last;
+        for (int i = 0; i + 1 < (MAT ? R : 1); i++) ROW[i] = ROW[i + 1];
+        ROW[MAT ? R - 1 : 0] = nxt;
+      } else {
+        const uint32_t last = pk::align16(nxt, OW[0]);
+#pragma unroll
+        for (int p = 0; p + 1 < RH; p++) OW[p] = OW[p + 1];
+        OW[RH - 1] = last;
+      }
     }
     // odd step: slot BK - 1 <- next lane's slot 0, slot R - 1 <- own slot R
     {
@@ -795,15 +847,18 @@ struct WaveFill16 {
       for (int p = 0; p < RH; p++)
       {
         cellpair<EK>(HO[p], UO[p], LO[p], bestO[p], btO[p], gebO[p], tfO[p], tlO[p], HALF == 0 ? accO[p] : acc2O[p],
-                     UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], OW[p], MW[p], tv1, clO[p]);
-        if (RL == 0) track_key<EK>(kbO[p], HO[p], tlO[p], tv1, k);
+                     UE[p], p == RH - 1 ? leftl : LE[p == RH - 1 ? p : p + 1], MAT ? ROW[MAT ? p : 0] : OW[p], MW[p], tv1, clO[p],
+                     MAT ? ROW[MAT ? p + RH : 0] : 0u);
+        if (TRK) track_key<EK>(kbO[p], HO[p], tlO[p], tv1, k);
       }
     }
     // mutant window moves on: first register <- (previous lane's last.hi | the pair's feeder, own last.lo)
     {
       const int mi = yfeed_m + it;
       const uint32_t fbm = Base::feed_byte(fm_lo, fm_hi, k);
-      const uint32_t feed = ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? fbm : SENT_M) << 16;
+      // (MAT: the letter arrives in a high half and is moved to the low half of the first register below: high-half code)
+      const uint32_t feed = (MAT ? ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? (MSEL | (fbm + 4u)) : MSENT_HI)
+                                 : ((!EDGE || (uint32_t)mi < (uint32_t)Y) ? fbm : SENT_M)) << 16;
       // ... together with the up offer of the next iteration's even step (one exchange)
       int32_t mv[2] = {(int32_t)MW[RH - 1], (int32_t)UO[RH - 1]};
       const int32_t mo[2] = {(int32_t)feed, (int32_t)NEGV};
@@ -811,7 +866,10 @@ struct WaveFill16 {
       uint32_t prv = (uint32_t)mv[0];
       up_prev = (uint32_t)mv[1];
       if (SEG) prv = segfirst ? feed : prv;
-      const uint32_t first = pk::align16(MW[RH - 1], prv);
+      uint32_t first = pk::align16(MW[RH - 1], prv);
+      // MAT: what moved from a high half into the low one sheds its + 4, what moved from a low half into the high one gains
+      // it (one 32-bit add: no half borrows, codes are 4 .. 12 in the low half here)
+      if (MAT) first += MADJ;
 #pragma unroll
       for (int p = RH - 1; p > 0; p--) MW[p] = MW[p - 1];
       MW[0] = first;
@@ -823,7 +881,7 @@ struct WaveFill16 {
 #pragma unroll
     for (int p = 0; p < RH; p++) { accE[p] = 0; accO[p] = 0; acc2E[p] = 0; acc2O[p] = 0; }
     uint32_t kb0E[RH], kb0O[RH];
-    if (RL == 0) {
+    if (TRK) {
 #pragma unroll
       for (int p = 0; p < RH; p++) {        // a later cell with the same score loses against 8 best + 7
         kb0E[p] = kbE[p] = pk::mad(bestE[p], SC4 ? C2 : C8, SEVEN); kb0O[p] = kbO[p] = pk::mad(bestO[p], SC4 ? C2 : C8, SEVEN);
@@ -835,7 +893,7 @@ struct WaveFill16 {
     for (int k = 0; k < 4; k++) iteration16<EK, 0>(8 * b + k, k);
 #pragma clang loop unroll_count(UNR)
     for (int k = 4; k < 8; k++) iteration16<EK, 1>(8 * b + k, k);
-    if (RL == 0) {
+    if (TRK) {
       // cell c of this block (iteration 8 b + c) is step 16 b + 2 c of an even slot, 16 b + 2 c + 1 of an odd one
       const uint32_t baseE = pk::both(16 * b + 14), baseO = pk::both(16 * b + 15);
 #pragma unroll
@@ -895,9 +953,16 @@ struct WaveFill16 {
   PW_FN int tbegin_of(int j) const {      // RULE != 0: the step of the diagonal's cell that may begin an alignment
     const int dd = li * BK + j, d = pd.dmin + dd;
     if (!valid || dd >= ndiag) return 32767;
-    if ((RL == 2 || a.brule == BRULE_ORIGIN) && d != 0) return 32767;   // begin at cell (0, 0) only (B_GLOBAL, GLOBAL, START_ANCHORED_OVERLAP)
+    if ((RL == 2 || RL == 5 || a.brule == BRULE_ORIGIN) && d != 0) return 32767;   // begin at cell (0, 0) only (B_GLOBAL, GLOBAL, START_ANCHORED, START_ANCHORED_OVERLAP)
     return (d < 0 ? -d : d) - pd.s0;                       // the first cell of the diagonal lies on the table edge
   }
+  // MAT: the row of origin letter l (uniform rows, selected by compares: scalar code where l is wave-uniform)
+  PW_FN uint32_t row_of(uint32_t l) const {
+    return l == 0u ? a.mat_rows[0] : (l == 1u ? a.mat_rows[1] : (l == 2u ? a.mat_rows[2] : (l == 3u ? a.mat_rows[3] : 0u)));
+  }
+  PW_FN uint32_t row_at(int i) const { return (uint32_t)i < (uint32_t)X ? row_of((uint32_t)oseq[i]) : 0u; }
+  PW_FN uint32_t msel_lo(int i) const { return (uint32_t)i < (uint32_t)Y ? (MSEL | (uint32_t)mseq[i]) : MSENT_LO; }
+  PW_FN uint32_t msel_hi(int i) const { return (uint32_t)i < (uint32_t)Y ? (MSEL | ((uint32_t)mseq[i] + 4u)) : MSENT_HI; }
   PW_FN uint32_t letter_o(int i) const { return (uint32_t)i < (uint32_t)X ? (uint32_t)oseq[i] : SENT_O; }
   PW_FN uint32_t letter_m(int i) const { return (uint32_t)i < (uint32_t)Y ? (uint32_t)mseq[i] : SENT_M; }
   PW_FN int blocked(int j) const { return li * BK + j == ndiag ? NEG16 : 0; }   // first diagonal above the band
@@ -928,10 +993,15 @@ struct WaveFill16 {
     NDELTA = pk::both(SCL * (a.mismatch - a.match)); MATCHV = pk::both(SCL * a.match);
     // the multipliers of the "not kept" values: 0 / 1 each, or (SC4) 0 / 2 for D and 0 / 4 for I
     GOV = pk::both(SC4 ? 2 * a.go : a.go); GOVI = pk::both(a.go);
+    BIASV = pk::both(a.mat_bias); MADJ = 0x0003fffcu;
+    if (MAT) {
+#pragma unroll
+      for (int i = 0; i < (MAT ? R : 1); i++) ROW[i] = row_at(xbase + i - 1);
+    }
 #pragma unroll
     for (int p = 0; p < RH; p++) {
       const int e0 = 2 * p, e1 = 2 * p + R, o0 = 2 * p + 1, o1 = 2 * p + 1 + R;
-      if (RL == 0) {
+      if (ANYB) {
         gebE[p] = pk::pack(SCL * a.ge + blocked(e0), SCL * a.ge + blocked(e1));
         gebO[p] = pk::pack(SCL * a.ge + blocked(o0), SCL * a.ge + blocked(o1));
         tfE[p] = pk::pack(tfirst_of(e0), tfirst_of(e1)); tfO[p] = pk::pack(tfirst_of(o0), tfirst_of(o1));
@@ -946,20 +1016,22 @@ struct WaveFill16 {
       HE[p] = UE[p] = LE[p] = HO[p] = UO[p] = LO[p] = NEGV;
       up_prev = NEGV; phase_l = 0; phase_r = 0;
       // rule 0: scores never go below 0, and a diagonal whose best stays 0 reports its first cell (score 0 on the table edge)
-      bestE[p] = bestO[p] = RL == 0 ? 0u : NEGV;
-      btE[p] = RL == 0 ? tfE[p] : 0u; btO[p] = RL == 0 ? tfO[p] : 0u;
+      // (rule 5: a best of 0 never wins -- the end cell must beat 0 -- so where it "was reached" does not matter)
+      bestE[p] = bestO[p] = TRK ? 0u : NEGV;
+      btE[p] = (TRK && ANYB) ? tfE[p] : 0u; btO[p] = (TRK && ANYB) ? tfO[p] : 0u;
       OW[p] = pk::pack((int32_t)letter_o(xbase + p - 1), (int32_t)letter_o(xbase + p + RH - 1));
-      MW[p] = pk::pack((int32_t)letter_m(ybase - p - 1), (int32_t)letter_m(ybase - p - RH - 1));
+      if (MAT) MW[p] = pk::pack((int32_t)msel_lo(ybase - p - 1), (int32_t)msel_hi(ybase - p - RH - 1));
+      else MW[p] = pk::pack((int32_t)letter_m(ybase - p - 1), (int32_t)letter_m(ybase - p - RH - 1));
     }
     // The planner's steady range allows a diagonal's LAST cell to be the last step of a steady block (every cell of
     // the block is still valid); rules 1 / 2 capture that cell, which only the edge body does: give up that block.
-    const int sb1 = RL == 0 ? wd.steady_b1 : wd.steady_b1 - 1;
+    const int sb1 = CAP ? wd.steady_b1 - 1 : wd.steady_b1;
     feed_issue(0);
     for (int b = 0; b < wd.nblocks; b++) {
       feed_commit(b);
       if (b + 1 < wd.nblocks) feed_issue(b + 1);
       if (b >= wd.steady_b0 && b < sb1) block16<0>(b);
-      else if (RL != 0) block16<3>(b);
+      else if (!ANYB) block16<3>(b);
       else if (b >= wd.steady_b0) block16<2>(b);                   // every diagonal has started, some may have ended
       else if (sb1 > wd.steady_b0) block16<1>(b);                  // some have not started; none has ended before the steady range
       else block16<3>(b);                                          // (no steady range: the planner's bounds cannot tell)
@@ -994,14 +1066,14 @@ struct WaveFill16 {
         int x = aa + (d > 0 ? d : 0), y = aa - (d < 0 ? d : 0);
         uint64_t k;
         bool ok = true;
-        if (RL != 0) {
+        if (CAP) {
           // `s` is the captured value of the diagonal's last cell (_banded_find_optimal, _pw_internals.c:364-414)
           const bool ends_right = d < X - Y;
           x = ends_right ? d + Y : X; y = ends_right ? Y : X - d;
           // ties: banded overlap takes the diagonals in ascending order, standard overlap the last column top-down and then
           // the last row left to right (_std_find_optimal: on the full band every diagonal ends on one of the two)
           k = endrule == END_STD_OVERLAP ? (uint64_t)(uint32_t)(x < X ? x : X + y) : (uint64_t)(uint32_t)dd;
-          if (RL == 2 || endrule == END_CORNER) ok = d == X - Y;      // end at cell (X, Y) only
+          if (RL == 2 || RL == 4 || endrule == END_CORNER) ok = d == X - Y;      // end at cell (X, Y) only
         } else if (endrule == END_STD_LOCAL) k = (uint64_t)(uint32_t)x * (uint64_t)(uint32_t)(Y + 1) + (uint64_t)(uint32_t)y;
         else k = ((uint64_t)(uint32_t)dd << 32) | (uint64_t)(uint32_t)aa;
         const bool better = ok && valid && dd < ndiag && (!have || s > cs || (s == cs && k < ck));

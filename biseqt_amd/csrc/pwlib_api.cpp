@@ -166,6 +166,7 @@ struct pw_batch {
   void* d_state[2] = {nullptr, nullptr}; // their per-diagonal state, double buffered (shared: pairs run one after another)
   int32_t st_pitch = 0;
   int packed_seg = 0, packed_rule = 0, packed_nw = 1;     // packed_nw: wavefronts per pair (K2a with the 16-bit body)
+  int packed_mat = 0;                                     // the packed kernel reads a substitution matrix (WaveFill16<.., MAT>)
   pw::WaveDesc* d_waves = nullptr;
   int64_t cells = 0, alg_bytes = 0;
   // device
@@ -261,6 +262,15 @@ int batch_build(pw_batch* b) {
     }
   }
   const double mt = b->subst[0], mm = L > 1 ? b->subst[1] : b->subst[0];
+  // the best and the worst substitution (any of them may be: the API accepts mismatch > match, and a matrix)
+  double smax = b->subst[0], smin = b->subst[0];
+  for (double v : b->subst) { smax = std::max(smax, v); smin = std::min(smin, v); }
+  if (b->simple) { smax = std::max(mt, mm); smin = std::min(mt, mm); }      // (L = 1: the mismatch score never occurs)
+  // An integer substitution matrix over at most 4 letters goes into the packed kernels as rows of bytes
+  // (WaveFill16<.., MAT>, _alnchoice_M reads subst_scores[o][m], _pw_internals.c:217-245): bytes subst - min, at most 127
+  // (times 4 under the scores-times-4 rule), and min <= 0 -- letters outside a sequence score the minimum and must not
+  // lift a cell that has not started.
+  const bool mat_ok = !b->simple && L <= 4 && integral && smin <= 0 && smax - smin <= 127 && !env_int("PWLIB_NO_PACKED_MAT", 0);
   pw::plan_rules(b->mode, b->type, &b->brule, &b->endrule);
   b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
   // ---- pass 1: per-pair plans (dptable_init arithmetic) and batch statistics ----
@@ -327,7 +337,9 @@ int batch_build(pw_batch* b) {
   b->use_f64 = (b->flags & PW_FLAG_FORCE_F64) || !integral || (double)maxspan * maxabs >= (double)(1 << 27);
   const bool bany = b->brule == pw::BRULE_ANY;
   const bool track = b->endrule == pw::END_STD_LOCAL || b->endrule == pw::END_BANDED_LOCAL;
-  if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || !b->simple || b->go > 0) b->variant = pw::VAR_GENERIC;
+  // (a matrix the packed kernels take: planned like match / mismatch scoring first; whatever does not end up on a packed
+  //  kernel falls back to the generic one below)
+  if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || (!b->simple && !mat_ok) || b->go > 0) b->variant = pw::VAR_GENERIC;
   else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
@@ -353,20 +365,27 @@ int batch_build(pw_batch* b) {
                                          (b->brule == pw::BRULE_EDGE && b->endrule == pw::END_CORNER))) prule = 1;
   // (B_GLOBAL, and standard-mode GLOBAL: the same begin / end rule on the band [-Y, X])
   else if (b->variant == pw::VAR_FAST && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_CORNER) prule = 2;
+  // (END_ANCHORED: begin anywhere like LOCAL, end at (X, Y) -- the captured last cell of one diagonal, nothing tracked)
+  else if (b->variant == pw::VAR_FAST_ANY_TRACK && b->endrule == pw::END_CORNER) prule = 4;
+  // (START_ANCHORED: begin at (0, 0) like GLOBAL, end at the first best cell, which must beat 0)
+  else if (b->variant == pw::VAR_FAST_TRACK && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_STD_LOCAL) prule = 5;
+  if (!b->simple && prule > 2) prule = -1;          // (the matrix form is built for rules 0 .. 3)
+  if (prule >= 4 && env_int("PWLIB_NO_PACKED_ANCHORED", 0)) prule = -1;
   bool pfits = false;
   // (any substitution may be the best one: the API accepts mismatch > match)
-  if (prule == 0) pfits = (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 8000;
+  if (prule == 0 || prule == 4) pfits = (double)maxmin * std::max(0.0, smax) <= 8000;
   else if (prule > 0) {
-    // real scores must stay above the values derived from the sentinel (<= -24000 + 100) and below int16's top
-    const double worst = std::max(0.0, -std::min(mt, mm));
+    // real scores must stay above the values derived from the sentinel (<= -24000 + 100) and below int16's top -- rule 5
+    // below 8192, the range of its running-best key
+    const double worst = std::max(0.0, -smin);
     const double lowest = (double)maxmin * worst + fabs(b->go) + fabs(b->ge) * (maxnd + 2);
-    const double highest = (double)maxmin * std::max(0.0, std::max(mt, mm));
-    pfits = lowest <= 23000 && highest <= 30000 && b->go <= 0 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
+    const double highest = (double)maxmin * std::max(0.0, smax);
+    pfits = lowest <= 23000 && highest <= (prule == 5 ? 8000 : 30000) && b->go <= 0 && !env_int("PWLIB_NO_PACKED_OVERLAP", 0);
   }
   // (a few standard-mode pairs: the strips, one pair after another, when they are estimated to finish before the 16-bit body
   //  on several wavefronts per pair would -- tests/micro/few_pairs.py: 2 kb x 2 kb, one pair 0.6 ms on the strips, 1.5 ms
   //  there; four pairs 2.3 ms and 1.6 ms)
-  const bool strips_win = latency_mode && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
+  const bool strips_win = latency_mode && b->simple && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
                           !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) && !(b->flags & PW_FLAG_NO_STRIP) &&
                           (double)maxspan * maxabs < (double)(1 << 25) && est_strips_ms < 0.9 * est_pmw_ms;
   if (prule >= 0 && pfits && !b->use_f64 &&
@@ -430,6 +449,10 @@ int batch_build(pw_batch* b) {
       }
     }
     if (pbk) b->variant = pw::VAR_FAST16;
+  }
+  if (!b->simple) {
+    if (b->variant == pw::VAR_FAST16) b->packed_mat = 1;
+    else b->variant = pw::VAR_GENERIC;              // a matrix off the packed kernels: substitution table in LDS
   }
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {
@@ -517,7 +540,8 @@ int batch_build(pw_batch* b) {
     const int ppw = pseg ? 64 / pnl : 1;
     b->packed_seg = pseg; b->packed_rule = prule;
     // rule 0, scores below 2048: the kernel that holds every score times 4 (WaveFill16, RULE 3)
-    if (prule == 0 && (double)maxmin * std::max(0.0, std::max(mt, mm)) <= 2047 && !env_int("PWLIB_NO_SCALED16", 0))
+    if (prule == 0 && (double)maxmin * std::max(0.0, smax) <= 2047 && !env_int("PWLIB_NO_SCALED16", 0) &&
+        (!b->packed_mat || 4 * (smax - smin) <= 127))
       b->packed_rule = 3;
     BkClass& c = b->classes[0];
     for (size_t i = 0; i < c.order.size(); i += ppw) {
@@ -712,8 +736,21 @@ int launch_packed_fill(pw_batch* b, hipStream_t st) {
   a.go = (int32_t)b->go; a.ge = (int32_t)b->ge;
   a.score_mul = b->score_mul;
   a.order = b->classes[0].d_order; a.waves = b->d_waves;
-  if (b->packed_nw > 1) HIP_TRY(pw::launch_fill16_mw(a, b->classes[0].bk, b->packed_rule, b->packed_nw, (int)b->waves.size(), st));
-  else HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, (int)b->waves.size(), st));
+  if (b->packed_mat) {
+    // rows of bytes scale * (subst[o][m] - min), m = 0 .. 3 from the low byte up; letters beyond L never occur
+    const int scale = b->packed_rule == 3 ? 4 : 1;
+    double smin = b->subst[0];
+    for (double v : b->subst) smin = std::min(smin, v);
+    for (int o = 0; o < 4; o++) {
+      uint32_t row = 0;
+      for (int m = 0; m < 4; m++)
+        if (o < b->L && m < b->L) row |= (uint32_t)(scale * (int)(b->subst[(size_t)o * b->L + m] - smin)) << (8 * m);
+      a.mat_rows[o] = row;
+    }
+    a.mat_bias = scale * (int)(-smin);
+  }
+  if (b->packed_nw > 1) HIP_TRY(pw::launch_fill16_mw(a, b->classes[0].bk, b->packed_rule, b->packed_mat, b->packed_nw, (int)b->waves.size(), st));
+  else HIP_TRY(pw::launch_fill16(a, b->classes[0].bk, b->packed_seg, b->packed_rule, b->packed_mat, (int)b->waves.size(), st));
   return 0;
 }
 
@@ -795,6 +832,7 @@ const char* pw_batch_kernel_name(const pw_batch* b) {
       else if (b->packed_rule == 3) snprintf(name, sizeof name, "k_fill16<%d, %s> x4", bk, b->packed_seg ? "true" : "false");
       else if (b->packed_rule) snprintf(name, sizeof name, "k_fill16<%d, %s, %d>", bk, b->packed_seg ? "true" : "false", b->packed_rule);
       else snprintf(name, sizeof name, "k_fill16<%d, %s>", bk, b->packed_seg ? "true" : "false");
+      if (b->packed_mat) strncat(name, " matrix", sizeof name - strlen(name) - 1);
       break;
     case pw::VAR_FAST_ANY_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, true, true, false>", t, bk); break;
     case pw::VAR_FAST_TRACK: snprintf(name, sizeof name, "k_fill<%s, %d, false, true, false>", t, bk); break;

@@ -148,11 +148,21 @@ void run_fill(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst
 }
 
 int g_packed_mode = 0;
+bool g_packed_mat = false;
 
 template <typename T, int BK> struct Run16 {
   static bool go(const pw::FillParams<T>&, const pw::PairDesc&) { return false; }
 };
 template <int BK> struct Run16<int32_t, BK> {
+  template <bool SEG, int RULE, bool MAT>
+  static void one(const pw::FillParams<int32_t>& a, const pw::WaveDesc& wd) {
+    Emu emu;
+    emu.run([&]() { pw::WaveFill16<EmuP, BK, SEG, RULE, MAT> w(a, wd); w.run(); });
+  }
+  template <int RULE, bool MAT>
+  static void seg_or_not(const pw::FillParams<int32_t>& a, const pw::WaveDesc& wd, bool seg) {
+    if (seg) one<true, RULE, MAT>(a, wd); else one<false, RULE, MAT>(a, wd);
+  }
   static bool go(const pw::FillParams<int32_t>& a, const pw::PairDesc& pd) {
     if constexpr (BK % 4 == 0) {
       // one pair in the wave, but on nl < 64 lanes: exercises the pair-boundary overrides of the lane-packed kernel
@@ -160,24 +170,29 @@ template <int BK> struct Run16<int32_t, BK> {
       memset(&wd, 0, sizeof wd);
       wd.first = 0; wd.count = 1; wd.nblocks = pd.nblocks; wd.steady_b0 = pd.steady_b0; wd.steady_b1 = pd.steady_b1;
       // packed16 == 1: lane-packed form on nl < 64 lanes; packed16 == 2: one pair per wave, uniform form
-      const bool seg = g_packed_mode == 1;
+      // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048); 4: the same, lane-packed
+      const bool seg = g_packed_mode == 1 || g_packed_mode == 4;
+      const bool x4 = g_packed_mode == 3 || g_packed_mode == 4;
       wd.nl = seg ? pd.nl : 64;
-      Emu emu;
-      const int rule = (a.endrule == pw::END_BANDED_OVERLAP || a.endrule == pw::END_STD_OVERLAP) ? 1
-                       : (a.endrule == pw::END_CORNER ? (a.brule == pw::BRULE_ORIGIN ? 2 : 1) : 0);
-      if (rule == 0) {
-        // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048)
-        // packed16 == 4: the same, lane-packed form
-        if (g_packed_mode == 4) { wd.nl = pd.nl; emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 3> w(a, wd); w.run(); }); }
-        else if (g_packed_mode == 3) emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 3> w(a, wd); w.run(); });
-        else if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 0> w(a, wd); w.run(); });
-        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 0> w(a, wd); w.run(); });
-      } else if (rule == 1) {
-        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 1> w(a, wd); w.run(); });
-        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 1> w(a, wd); w.run(); });
-      } else {
-        if (seg) emu.run([&]() { pw::WaveFill16<EmuP, BK, true, 2> w(a, wd); w.run(); });
-        else emu.run([&]() { pw::WaveFill16<EmuP, BK, false, 2> w(a, wd); w.run(); });
+      const bool local_end = a.endrule == pw::END_STD_LOCAL || a.endrule == pw::END_BANDED_LOCAL;
+      int rule;
+      if (a.brule == pw::BRULE_ANY) rule = local_end ? (x4 ? 3 : 0) : 4;                 // LOCAL / B_LOCAL; END_ANCHORED
+      else if (local_end) rule = 5;                                                     // START_ANCHORED
+      else if (a.endrule == pw::END_BANDED_OVERLAP || a.endrule == pw::END_STD_OVERLAP) rule = 1;
+      else rule = a.brule == pw::BRULE_ORIGIN ? 2 : 1;                                  // END_CORNER: global, or END_ANCHORED_OVERLAP
+      const bool mat = g_packed_mat;
+      switch (rule * 2 + (mat ? 1 : 0)) {
+        case 0: seg_or_not<0, false>(a, wd, seg); break;
+        case 1: seg_or_not<0, true>(a, wd, seg); break;
+        case 2: seg_or_not<1, false>(a, wd, seg); break;
+        case 3: seg_or_not<1, true>(a, wd, seg); break;
+        case 4: seg_or_not<2, false>(a, wd, seg); break;
+        case 5: seg_or_not<2, true>(a, wd, seg); break;
+        case 6: seg_or_not<3, false>(a, wd, seg); break;
+        case 7: seg_or_not<3, true>(a, wd, seg); break;
+        case 8: seg_or_not<4, false>(a, wd, seg); break;
+        case 10: seg_or_not<5, false>(a, wd, seg); break;
+        default: return false;
       }
       return true;
     } else {
@@ -239,7 +254,13 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   a.npairs = 1; a.L = L; a.brule = pl.brule; a.endrule = pl.endrule; a.banded = (mode == pw::BANDED_MODE);
   a.match = sub[0]; a.mismatch = L > 1 ? sub[1] : sub[0]; a.go = (T)go; a.ge = (T)ge;
   a.score_mul = 1.0;
-  const int generic = force_generic || !simple || go > 0 || hdump != nullptr;
+  // a small integer matrix may go through the packed kernels' matrix form (the product's admission: pwlib_api.cpp)
+  double smin = subst[0], smax = subst[0];
+  bool integral = true;
+  for (int i = 0; i < L * L; i++) { smin = subst[i] < smin ? subst[i] : smin; smax = subst[i] > smax ? subst[i] : smax; integral = integral && subst[i] == (double)(int)subst[i]; }
+  const bool x4mode = packed16 == 3 || packed16 == 4;
+  const bool mat16 = packed16 && !simple && L <= 4 && integral && smin <= 0 && (x4mode ? 4 : 1) * (smax - smin) <= 127 && sizeof(T) == 4;
+  const int generic = force_generic || (!simple && !mat16) || go > 0 || hdump != nullptr;
   const int bany = pl.brule == pw::BRULE_ANY;
   const int track = pl.endrule == pw::END_STD_LOCAL || pl.endrule == pw::END_BANDED_LOCAL;
   const bool rule_local = bany && track;
@@ -247,8 +268,21 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
                             (pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_STD_OVERLAP) ||
                             (pl.brule == pw::BRULE_EDGE && pl.endrule == pw::END_CORNER);
   const bool rule_global = pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_CORNER;      // B_GLOBAL, and GLOBAL on the full band
-  const int use16 = packed16 && !generic && (rule_local || rule_overlap || rule_global) && bk % 4 == 0 && sizeof(T) == 4;
+  const bool rule_anchored = !mat16 && ((bany && pl.endrule == pw::END_CORNER) ||             // END_ANCHORED
+                                        (pl.brule == pw::BRULE_ORIGIN && pl.endrule == pw::END_STD_LOCAL));   // START_ANCHORED
+  const int use16 = packed16 && !generic && (rule_local || rule_overlap || rule_global || rule_anchored) && bk % 4 == 0 && sizeof(T) == 4;
   g_packed_mode = packed16;
+  g_packed_mat = mat16;
+  if (mat16) {
+    const int scale = x4mode ? 4 : 1;
+    for (int o = 0; o < 4; o++) {
+      uint32_t row = 0;
+      for (int m = 0; m < 4; m++) if (o < L && m < L) row |= (uint32_t)(scale * (int)(subst[o * L + m] - smin)) << (8 * m);
+      a.mat_rows[o] = row;
+    }
+    a.mat_bias = scale * (int)(-smin);
+  }
+  if (packed16 && !generic && !use16) return -5;                   // the caller asked for a packed kernel that does not exist
   if (use16) pd.nl = (pl.ndiag + bk - 1) / bk;
   switch (bk) {
     case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, use16); break;
@@ -256,6 +290,9 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
     case 8: dispatch_variant<T, 8>(a, pd, sub.data(), generic, bany, track, use16); break;
     case 16: dispatch_variant<T, 16>(a, pd, sub.data(), generic, bany, track, use16); break;
     case 32: dispatch_variant<T, 32>(a, pd, sub.data(), generic, bany, track, use16); break;
+    // (lane widths only the packed kernels are built for)
+    case 12: if (!use16 || !Run16<T, 12>::go(a, pd)) return -4; break;
+    case 20: if (!use16 || !Run16<T, 20>::go(a, pd)) return -4; break;
     default: return -4;
   }
   // traceback by "one lane"

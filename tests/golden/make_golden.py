@@ -11,7 +11,7 @@ Files written:
                        pw.py:11-21 docstring example, plus the non-Gotoh witness of SURVEY.md section 7
   random_matrix.json.gz  random problems: {7 STD types, 3 banded types} x go {<0,0,>0} x ge x |alphabet|
                        x lengths 0..64 x random bands (clamped / infeasible) x sub-frames
-  float_logodds.json   log-odds float scores (formula of stochastics.py:305-309) at the five noise
+  float_logodds.json   log-odds float scores (the reference's own MutationProcess.log_odds_scores, stochastics.py:234-310) at the five noise
                        levels of tests/test_pw.py:106; scores stored as exact hex floats
   config_sized.json    config-sized spot checks: 1 kb global, 2 kb r=200 B_LOCAL pairs, 5 kb B_OVERLAP
 
@@ -167,17 +167,24 @@ def random_matrix(n=3000, seed=12345):
     return recs
 
 
-def log_odds(err, L=4):
-    """The formula of the reference's MutationProcess.log_odds_scores (stochastics.py:295-309) for
-    subst_probs=err, go_prob=err, ge_prob=err, uniform null hypothesis."""
-    any_subst = float(err)
-    each = any_subst / (L - 1)
-    match = 1 - any_subst
-    probs = [[match if i == j else each for j in range(L)] for i in range(L)]
-    null = [1. / L] * L
-    S = [[math.log(1 - err) + math.log(probs[i][j]) - math.log(null[j]) for j in range(L)]
-         for i in range(L)]
-    return S, math.log(err) - math.log(err), math.log(err)
+_REF_STOCHASTICS = None
+
+
+def log_odds(err, go_prob=None):
+    """Log-odds scores from the reference's OWN `MutationProcess.log_odds_scores`
+    (`/root/reference/biseqt/stochastics.py:234-310`, imported here -- it runs under python 3 unchanged; nothing is written
+    next to it) for subst_probs = ge_prob = err over ACGT, uniform null hypothesis; go_prob = err unless given."""
+    global _REF_STOCHASTICS
+    if _REF_STOCHASTICS is None:
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, '/root/reference')
+        import biseqt.sequence as RS
+        import biseqt.stochastics as RT
+        _REF_STOCHASTICS = (RS, RT)
+    RS, RT = _REF_STOCHASTICS
+    M = RT.MutationProcess(RS.Alphabet('ACGT'), subst_probs=err, go_prob=err if go_prob is None else go_prob, ge_prob=err)
+    S, (go, ge) = M.log_odds_scores()
+    return [[float(v) for v in row] for row in S], float(go), float(ge)
 
 
 def float_logodds(seed=777):
@@ -186,7 +193,7 @@ def float_logodds(seed=777):
     for err in (1e-2, 1e-1, 2e-1, 3e-1, 4e-1):
         S, go, ge = log_odds(err)
         # an affine variant too (go_prob < ge_prob), which tests/test_pw.py never exercises
-        go2 = math.log(err / 2) - math.log(err)
+        go2 = log_odds(err, go_prob=err / 2)[1]
         for rep in range(6):
             origin = rng.integers(0, 4, 100).tolist()
             mutant = synth.mutate(rng, np.array(origin, np.uint8), err, err, err, 4).tolist()

@@ -75,17 +75,17 @@ def test_packed_kernels_hold_their_occupancy_without_scratch():
     """The instantiations build.py holds to an occupancy (FILL16_WAVES: BK = 8 local rules at 5 wavefronts per SIMD, BK = 16
     at 3) must fit it WITHOUT scratch -- a spilling schedule is slower than the default one -- and use no AGPRs (on gfx950
     they come out of the same 512-register budget)."""
-    for (bk, rule), (occ, occ_seg) in sorted(B.FILL16_WAVES.items()):
-        md = _md('pw_fill16_bk%d_r%d.o' % (bk, rule))
+    for (bk, rule, mat), (occ, occ_seg) in sorted(B.FILL16_WAVES.items()):
+        md = _md('pw_fill16_bk%d_r%d%s.o' % (bk, rule, '_mat' if mat else ''))
         for seg, waves in ((False, occ), (True, occ_seg)):
             if not waves:
                 continue
-            k = md['k_fill16<%d, %s, %d>' % (bk, 'true' if seg else 'false', rule)]
+            k = md['k_fill16<%d, %s, %d, %s>' % (bk, 'true' if seg else 'false', rule, 'true' if mat else 'false')]
             assert k['private_segment_fixed_size'] == 0 and k['vgpr_spill_count'] == 0, (bk, rule, seg, k)
             assert k['agpr_count'] == 0, (bk, rule, seg, k)
             assert k['vgpr_count'] <= _vgpr_ceiling(waves), (bk, rule, seg, waves, k['vgpr_count'])
     # config 2's kernel by name: k_fill16<8, false, 3> ("x4") at 5 wavefronts per SIMD
-    assert B.FILL16_WAVES[(8, 3)][0] == 5 and B.FILL16_WAVES[(8, 0)][0] == 5
+    assert B.FILL16_WAVES[(8, 3, 0)][0] == 5 and B.FILL16_WAVES[(8, 0, 0)][0] == 5
 
 
 def test_packed_kernels_up_to_28_diagonals_per_lane_never_touch_scratch():
@@ -93,9 +93,9 @@ def test_packed_kernels_up_to_28_diagonals_per_lane_never_touch_scratch():
     for bk in B.PACKED_BKS:
         if bk > 28:
             continue
-        for rule in (0, 1, 2, 3):
-            md = _md('pw_fill16_bk%d_r%d.o' % (bk, rule))
-            k = md['k_fill16<%d, false, %d>' % (bk, rule)]
+        for rule, mat in [(r, 0) for r in B.PACKED_RULES] + [(r, 1) for r in B.PACKED_MAT_RULES]:
+            md = _md('pw_fill16_bk%d_r%d%s.o' % (bk, rule, '_mat' if mat else ''))
+            k = md['k_fill16<%d, false, %d, %s>' % (bk, rule, 'true' if mat else 'false')]
             assert k['private_segment_fixed_size'] == 0 and k['vgpr_spill_count'] == 0, (bk, rule, k)
 
 
@@ -109,7 +109,7 @@ def test_an_occupancy_bound_that_spills_is_caught():
         cmd = [('-DPW_FILL16_WAVES=6' if a.startswith('-DPW_FILL16_WAVES=') else a) for a in cmd]
         cmd[cmd.index('-o') + 1] = out
         subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        md = {n: k for n, k in codeobj.kernel_metadata(out).items() if 'k_fill16<8, false, 3>' in n}
+        md = {n: k for n, k in codeobj.kernel_metadata(out).items() if 'k_fill16<8, false, 3, false>' in n}
     (k,) = md.values()
     assert k['private_segment_fixed_size'] > 0 or k['vgpr_spill_count'] > 0 or k['vgpr_count'] > _vgpr_ceiling(6), k
 

@@ -251,3 +251,137 @@ def test_emu_strip_pipeline(oracle):
             assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
         n += 1
     assert n == 84
+
+
+def _random_matrix(rng, L, kind):
+    """An integer substitution matrix the packed kernels admit (minimum <= 0, range <= 127; `kind` 1: range <= 31 so that
+    the scores-times-4 form takes it too)."""
+    hi = 7 if kind else 40
+    S = rng.integers(-hi, hi + 1, size=(L, L))
+    S[np.arange(L), np.arange(L)] = rng.integers(1, hi + 1, size=L)           # matches usually score
+    if rng.random() < 0.3:
+        S = (S + S.T) // 2                                                     # symmetric, like real matrices
+    if rng.random() < 0.15:
+        S[int(rng.integers(0, L)), int(rng.integers(0, L))] = hi + 2           # a mismatch that beats every match
+    if S.min() > 0:
+        S[0, L - 1] = 0
+    return [[float(v) for v in row] for row in S]
+
+
+def test_emu_packed16_substitution_matrix(oracle):
+    """The packed kernel body with a substitution matrix (WaveFill16<.., MAT>: rows of bytes in the origin window, byte
+    selectors in the mutant window, one byte permute per cell pair) against the oracle: rules 0 .. 3, both lane layouts,
+    alphabets of 2 .. 4 letters, asymmetric matrices, clamped bands, empty and sub-word sequences."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(31)
+    n = 0
+    seen = set()
+    for trial in range(160):
+        L = int(rng.choice([2, 3, 4]))
+        X = int(rng.integers(0, 260)) if trial % 5 else int(rng.integers(0, 12))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        kind = trial % 3
+        if kind == 0:
+            m = synth.mutate(rng, o, 0.1, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 9))).astype(np.uint8)
+        elif kind == 1 and X > 0:
+            k = int(rng.integers(0, X + 1))
+            m = np.concatenate([o[k:], rng.integers(0, L, int(rng.integers(0, 60))).astype(np.uint8)])
+        else:
+            m = rng.integers(0, L, int(rng.integers(0, 200))).astype(np.uint8)
+        small = trial % 2
+        subst = _random_matrix(rng, L, small)
+        kw = dict(L=L, subst=subst, go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
+        which = trial % 8
+        if which < 3:                                          # B_LOCAL / LOCAL
+            if rng.random() < 0.7:
+                r, c = int(rng.integers(1, 50)), int(rng.integers(-10, 10))
+                kw.update(mode=1, alntype=1, diag_range=(c - r, c + r))
+            else:
+                kw.update(mode=0, alntype=1)
+        elif which < 5:                                        # B_OVERLAP / B_GLOBAL
+            alntype = 2 if which == 3 else 0
+            if alntype == 0 and rng.random() < 0.8:
+                lo, hi = min(0, X - len(m)) - int(rng.integers(0, 20)), max(0, X - len(m)) + int(rng.integers(0, 20))
+            else:
+                r, c = int(rng.integers(0, 50)), int(rng.integers(-10, 10))
+                lo, hi = c - r, c + r
+            kw.update(mode=1, alntype=alntype, diag_range=(lo, hi))
+        else:                                                  # standard GLOBAL / OVERLAP / START_- / END_ANCHORED_OVERLAP
+            kw.update(mode=0, alntype=(0, 4, 5, 6)[trial % 4])
+            if X + len(m) + 1 > 64 * 20:
+                continue
+        if kw['mode'] == 1:
+            nd = min(kw['diag_range'][1], X) - max(kw['diag_range'][0], -len(m)) + 1
+        else:
+            nd = X + len(m) + 1
+        bk = next((b for b in (4, 8, 16, 20, 32) if b >= (4, 8, 16)[trial % 3] and 64 * b >= nd), None)
+        if bk is None:
+            continue
+        a = oracle.solve(o, m, **kw)
+        modes = [1 + (trial // 8) % 2]
+        if which < 3 and small and min(X, len(m)) * max(max(map(max, subst)), 0) <= 2047:
+            modes += [3, 4]                                    # the scores-times-4 form, both layouts
+        for pk in modes:
+            b = emu.solve(o, m, bk=bk, packed16=pk, **kw)
+            for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+                assert a.get(key) == b.get(key), (trial, pk, key, a.get(key), b.get(key), kw, bk)
+            seen.add((which, pk))
+        n += 1
+    assert n > 120 and len(seen) >= 16, (n, sorted(seen))
+
+
+def test_emu_packed16_matrix_equals_match_mismatch_form(oracle):
+    """Match / mismatch scores written out as a 4 x 4 matrix whose fourth letter (which never occurs in the sequences) has
+    other scores: the batch is a matrix batch -- it takes the matrix form -- and must give the plain form's results."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(32)
+    for trial in range(24):
+        o = rng.integers(0, 3, int(rng.integers(30, 300))).astype(np.uint8)
+        m = synth.mutate(rng, o, 0.1, 0.05, 0.3, 3)
+        match, mismatch = float(rng.choice([1, 2, 5])), float(rng.choice([0, -1, -3]))
+        subst = [[match if i == j else mismatch for j in range(4)] for i in range(4)]
+        subst[3][0] = subst[0][3] = mismatch - 2.0
+        r, c = int(rng.integers(1, 40)), int(rng.integers(-8, 8))
+        base = dict(L=4, mode=1, alntype=trial % 3, diag_range=(min(c - r, 0, len(o) - len(m)), max(c + r, 0, len(o) - len(m))),
+                    go=float(rng.choice([0, -2, -5])), ge=float(rng.choice([-1, -2])))
+        a = emu.solve(o, m, bk=8, packed16=2, subst=subst, **base)
+        b = emu.solve(o, m, bk=8, packed16=2, match=match, mismatch=mismatch, **base)
+        ref = oracle.solve(o, m, match=match, mismatch=mismatch, **base)
+        for key in ('opt', 'score', 'transcript', 'origin_idx', 'mutant_idx'):
+            assert a.get(key) == ref.get(key) == b.get(key), (trial, key)
+
+
+def test_emu_packed16_anchored_rules(oracle):
+    """START_ANCHORED (begin at (0, 0), end at the first best cell, which must beat 0) and END_ANCHORED (begin anywhere,
+    end at (X, Y)) on their own packed instantiations (WaveFill16 rules 5 and 4) against the oracle: related, unrelated
+    and suffix-prefix pairs, empty sequences, negative match scores, both lane layouts."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(45)
+    n = 0
+    for trial in range(160):
+        L = int(rng.choice([2, 4]))
+        X = int(rng.integers(0, 200)) if trial % 5 else int(rng.integers(0, 4))
+        o = rng.integers(0, L, X).astype(np.uint8)
+        kind = trial % 4
+        if kind == 0:
+            m = rng.integers(0, L, int(rng.integers(0, 200))).astype(np.uint8)
+        elif kind == 1 and X > 10:
+            k = int(rng.integers(0, X))
+            m = np.concatenate([o[k:], rng.integers(0, L, int(rng.integers(0, 60))).astype(np.uint8)])
+        elif kind == 2 and X > 10:
+            k = int(rng.integers(1, X))
+            m = np.concatenate([rng.integers(0, L, int(rng.integers(0, 40))).astype(np.uint8), o[:k]])
+        else:
+            m = synth.mutate(rng, o, 0.08, 0.05, 0.3, L) if X else rng.integers(0, L, int(rng.integers(0, 5))).astype(np.uint8)
+        kw = dict(L=L, mode=0, alntype=2 + trial % 2, match=float(rng.choice([1, 2, 5, -1])), mismatch=float(rng.choice([0, -1, -3, 2])),
+                  go=float(rng.choice([0, -1, -5])), ge=float(rng.choice([0, -1, -2])))
+        nd = X + len(m) + 1
+        bk = next((b for b in (4, 8, 12, 16, 20) if b >= (4, 8, 12)[trial % 3] and 64 * b >= nd), None)
+        if bk is None:
+            continue
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, bk=bk, packed16=1 + (trial // 2) % 2, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk, X, len(m))
+        n += 1
+    assert n > 140

@@ -195,3 +195,79 @@ def test_abandoned_strip_pipeline_is_solved_again(oracle, monkeypatch):
             monkeypatch.delenv('PWLIB_STRIP_SPIN_LIMIT')
             res4 = b.run()
             check(res4, b.transcripts(res4))
+
+
+BLASTISH = [[2, -3, -1, -3], [-3, 2, -3, -1], [-1, -3, 2, -3], [-3, -1, -3, 2]]       # transitions cost less than transversions
+ASYM = [[5, -4, -2, 0], [-3, 4, -1, -6], [-2, -2, 6, -3], [1, -5, -4, 3]]             # asymmetric, one positive mismatch
+WIDE = [[40, -30, -60, -35], [-30, 45, -25, -70], [-60, -25, 50, -20], [-35, -70, -20, 42]]   # range 120: unscaled form only
+
+
+@pytest.mark.parametrize('mode,alntype,dr', [(1, 1, (-40, 35)), (1, 2, (-50, 50)), (1, 0, (-60, 60)), (0, 1, None),
+                                             (0, 0, None), (0, 4, None), (0, 6, None)],
+                         ids=['B_LOCAL', 'B_OVERLAP', 'B_GLOBAL', 'LOCAL', 'GLOBAL', 'OVERLAP', 'END_ANCHORED_OVERLAP'])
+def test_integer_substitution_matrix_on_the_packed_kernels(oracle, mode, alntype, dr):
+    """A 4 x 4 (3 x 3, 2 x 2) integer substitution matrix runs on the packed 16-bit kernels (rows of bytes + one byte permute
+    per cell pair) instead of the generic kernel: the kernel name says so, and every record and transcript equals the forced
+    generic kernel's and, on a sample, the oracle's (_alnchoice_M: subst_scores[o][m], 'M' iff the letters are equal)."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3400 + 10 * mode + alntype)
+    for subst, L, go, ge in ((BLASTISH, 4, -5, -2), (ASYM, 4, 0, -3), (WIDE, 4, -20, -5), ([[3, -2, -4], [-1, 2, -3], [-4, -3, 5]], 3, -2, -1),
+                             ([[1, -1], [-2, 2]], 2, -1, -1)):
+        pairs = _pairs(rng, 320, 0 if L == 3 else 20, 400 if mode else 200, L=L)
+        if subst is WIDE:                                   # scores up to 50 per letter: keep min(X, Y) * 50 below 8000
+            pairs = [(o[:150], m[:150]) for o, m in pairs]
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, subst_scores=subst, go_score=go, ge_score=ge)
+        if dr is not None:
+            kw['diag_range'] = dr
+        name, dtype, res, txs, rcs = _run(pairs, **kw)
+        nameg, _, resg, txsg, _ = _run(pairs, flags=W.PW_FLAG_FORCE_GENERIC, **kw)
+        assert 'k_fill16' in name and 'matrix' in name, (name, kw)
+        assert 'k_fill16' not in nameg, nameg
+        assert (res == resg).all() and txs == txsg, (name, kw)
+        okw = dict(L=L, mode=mode, alntype=alntype, diag_range=dr, subst=[[float(v) for v in row] for row in subst], go=go, ge=ge)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, 13, (name, kw))
+        if (mode, alntype) in ((1, 1), (0, 1)):
+            # the scores-times-4 form: running scores below 2048 and 4 x the matrix's range within a byte's 127
+            smax, smin = max(map(max, subst)), min(map(min, subst))
+            longest = max(min(len(o), len(m)) for o, m in pairs)
+            assert ('x4' in name) == (longest * max(smax, 0) <= 2047 and 4 * (smax - smin) <= 127), name
+
+
+def test_matrices_the_packed_kernels_do_not_take(oracle):
+    """Outside the admission (five letters, a range above 127, every score positive, go > 0) a matrix batch keeps the generic
+    kernel -- and still equals the oracle."""
+    from biseqt_amd import synth
+    rng = synth.rng_for(3477)
+    cases = [([[1 if i == j else -1 - (i + j) % 3 for j in range(5)] for i in range(5)], 5, -2),
+             ([[100, -90, 0, 0], [-90, 100, 0, 0], [0, 0, 100, -90], [0, 0, -90, 100]], 4, -2),
+             ([[5, 1, 2, 1], [1, 5, 1, 2], [2, 1, 5, 1], [1, 2, 1, 5]], 4, -2),
+             (BLASTISH, 4, 2)]
+    for subst, L, go in cases:
+        pairs = _pairs(rng, 300, 10, 60, L=L)
+        kw = dict(alnmode=1, alntype=1, alphabet_len=L, diag_range=(-20, 20), subst_scores=subst, go_score=go, ge_score=-1)
+        name, dtype, res, txs, rcs = _run(pairs, **kw)
+        assert 'k_fill16' not in name, name
+        okw = dict(L=L, mode=1, alntype=1, diag_range=(-20, 20), subst=[[float(v) for v in row] for row in subst], go=go, ge=-1)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, 17, name)
+
+
+@pytest.mark.parametrize('alntype,tag', [(2, ', 5>'), (3, ', 4>')], ids=['START_ANCHORED', 'END_ANCHORED'])
+def test_anchored_types_on_their_packed_kernels(oracle, alntype, tag):
+    """START_ANCHORED and END_ANCHORED (_alnchoice_B :161-209, _std_find_optimal :303-360) have their own packed
+    instantiations (WaveFill16 rules 5 / 4): named, equal to the 32-bit kernels for every pair, and to the oracle on a sample
+    -- many pairs (throughput layout), a few (latency layouts), with related, unrelated, suffix-prefix and empty pairs."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3500 + alntype)
+    for n, (match, mismatch, go, ge) in ((1200, (2, -3, -4, -1)), (300, (1, -1, 0, -1)), (40, (5, -4, -10, -1)), (1100, (-1, 1, -2, -1))):
+        pairs = _pairs(rng, n, 0, 500 if n > 100 else 1500)
+        kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, match_score=match, mismatch_score=mismatch, go_score=go, ge_score=ge)
+        name, dtype, res, txs, rcs = _run(pairs, **kw)
+        name32, _, res32, txs32, _ = _run(pairs, flags=W.PW_FLAG_NO_PACKED16, **kw)
+        assert 'k_fill16' not in name32, name32
+        if n > 256:
+            assert 'k_fill16' in name and tag in name, (name, n)
+        assert (res == res32).all() and txs == txs32, (name, kw)
+        okw = dict(L=4, mode=0, alntype=alntype, match=match, mismatch=mismatch, go=go, ge=ge)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, max(1, n // 40), (name, kw))

@@ -139,6 +139,28 @@ def test_log_odds_scores_formula_and_signs():
         MutationProcess(A, subst_probs=.1, go_prob=.3, ge_prob=.2)
 
 
+def test_log_odds_scores_equal_the_reference_fixture():
+    """`MutationProcess.log_odds_scores` against values computed by the reference's own function
+    (/root/reference/biseqt/stochastics.py:234-310; tests/golden/logodds_reference.json, generated by
+    tests/golden/make_logodds_golden.py importing it): the five noise levels of the reference's tests/test_pw.py:106,
+    alphabets of 2 / 4 / 20 letters, linear and affine gap models, uniform and own null hypotheses -- every score equal
+    as a bit pattern.  These are the float scores the f64 DP path is fed with."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'logodds_reference.json')) as f:
+        recs = json.load(f)['records']
+    assert len(recs) >= 60
+    for k, rec in enumerate(recs):
+        A = Alphabet(rec['letters'])
+        sp = rec['subst_probs']
+        sp = float.fromhex(sp) if isinstance(sp, str) else [[float.fromhex(v) for v in row] for row in sp]
+        M = MutationProcess(A, subst_probs=sp, go_prob=float.fromhex(rec['go_prob']), ge_prob=float.fromhex(rec['ge_prob']))
+        null = None if rec['null'] is None else [float.fromhex(v) for v in rec['null']]
+        S, (go, ge) = M.log_odds_scores(null_hypothesis=null) if null is not None else M.log_odds_scores()
+        assert [[float(v).hex() for v in row] for row in S] == rec['subst_scores'], (k, rec['tag'])
+        assert (float(go).hex(), float(ge).hex()) == (rec['go_score'], rec['ge_score']), (k, rec['tag'])
+
+
 def test_mutate_transcript_is_consistent():
     A = Alphabet('ACGT')
     rng = np.random.default_rng(3)

@@ -171,3 +171,33 @@ def test_large_pair_properties(A):
     order = np.lexsort((j, i, key))
     assert (order == np.arange(nrows)).all()
     assert planted >= 30000 - k + 1
+
+
+def test_gpu_seeds_equal_the_reference_seed_lists(A):
+    """The GPU seed enumeration against seed lists and band counts computed by the reference's OWN in-memory enumeration
+    (`WordBlotOverlapRef.seeds` / `seed_count`, blot.py:607-642; tests/golden/seed_lists_reference.json.gz, generated by
+    importing the reference): the in-memory class row for row in its (j, i) order, `SeedIndex` as the same set."""
+    import hashlib
+    from biseqt_amd.blot import WordBlotOverlapRef
+    from biseqt_amd.seeds import SeedIndex
+    from tests.helpers import dec, load_golden
+    recs = load_golden('seed_lists_reference.json.gz')
+    done = 0
+    for k, rec in enumerate(recs):
+        S, T, w = dec(rec['S']), dec(rec['T']), rec['wordlen']
+        if len(S) < w or len(T) < w:
+            assert rec['seeds_ij_n'] == 0                   # (sequences shorter than the word: no k-mers at all)
+            continue
+        WB = WordBlotOverlapRef(_seq(A, S), wordlen=w, alphabet=A, g_max=0.2, sensitivity=0.9)
+        WB._set_query(_seq(A, T))
+        rows = [(int(i), int(j)) for i, j in WB.seeds()]
+        assert len(rows) == rec['seeds_ij_n'], k
+        assert hashlib.sha256(','.join('%d:%d' % r for r in rows).encode()).hexdigest() == rec['seeds_ij_sha256'], k
+        for b in rec['band_counts']:
+            assert WB.seed_count(d_band=tuple(b['d_band'])) == b['count_d'], (k, b)
+            assert WB.seed_count(d_band=tuple(b['d_band']), a_band=tuple(b['a_band'])) == b['count_da'], (k, b)
+        idx = SeedIndex(_seq(A, S), _seq(A, T), wordlen=w, alphabet=A)
+        assert sorted((int(i), int(j)) for i, j in idx.seeds(exclude_trivial=True)) == sorted(rows), k
+        idx.close()
+        done += 1
+    assert done >= 50

@@ -97,3 +97,39 @@ def test_in_memory_variant_is_the_same_set():       # blot.py:607-620 against se
     assert sorted(SO.seeds(rows, sc)) == sorted(SO.seeds_by_mutant(S, T, 4, 4))
     rows, sc = SO.seed_rows(S, S, 4, 4)
     assert sorted(SO.seeds(rows, sc, exclude_trivial=True)) == sorted(SO.seeds_by_mutant(S, S, 4, 4))
+
+
+def _rows_ok(rec, key, rows):
+    import hashlib
+    rows = [(int(i), int(j)) for i, j in rows]
+    assert len(rows) == rec[key + '_n'], (key, len(rows), rec[key + '_n'])
+    assert hashlib.sha256(','.join('%d:%d' % r for r in rows).encode()).hexdigest() == rec[key + '_sha256'], key
+    if key in rec:
+        assert [list(r) for r in rows] == rec[key], key
+
+
+def test_oracle_equals_the_reference_seed_lists():
+    """Seed lists and band counts computed by the reference's OWN in-memory enumeration (`WordBlotOverlapRef.seeds` /
+    `seed_count`, blot.py:607-642; fixture generated by tests/golden/make_logodds_golden.py importing the reference) for
+    64 seeded pairs -- related, unrelated, repeats, two-letter sequences, self comparisons, sequences shorter than the
+    word: the oracle's enumeration must give the same rows in the same order, and its table rows the same set."""
+    from tests.helpers import dec, load_golden
+    recs = load_golden('seed_lists_reference.json.gz')
+    assert len(recs) >= 50
+    n_rows = 0
+    for k, rec in enumerate(recs):
+        S, T, w = dec(rec['S']), dec(rec['T']), rec['wordlen']
+        got = SO.seeds_by_mutant(S, T, w, 4)
+        _rows_ok(rec, 'seeds_ij', got)
+        n_rows += len(got)
+        if 'seeds_ij_with_trivial_n' in rec:
+            _rows_ok(rec, 'seeds_ij_with_trivial', SO.seeds_by_mutant(S, T, w, 4, exclude_trivial=False))
+        # the SQL-table presentation (seeds.py:117-197) lists the same seeds in another order
+        rows, sc = SO.seed_rows(S, T, w, 4)
+        assert sorted(SO.seeds(rows, sc, exclude_trivial=True)) == sorted(got), k
+        for b in rec['band_counts']:
+            (d0, d1), (a0, a1) = b['d_band'], b['a_band']
+            da = [SO.to_diagonal_coordinates(i, j) for i, j in got]
+            assert sum(1 for d, a in da if d0 <= d <= d1) == b['count_d'], k
+            assert sum(1 for d, a in da if d0 <= d <= d1 and a0 <= a <= a1) == b['count_da'], k
+    assert n_rows > 50000
