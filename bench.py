@@ -183,6 +183,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the serial / e2e / variant legs (profiling runs)')
     ap.add_argument('--force-dist', action='store_true', help='run the RCCL gather path even with one rank (self-test)')
+    ap.add_argument('--gather', choices=('packed', 'slots'), default='packed',
+                    help='what the transcript gather moves: the ops compacted on the device (pw_batch_pack_transcripts, about '
+                         'half the bytes; they follow one use of the batch later, when their size is known) or the X + Y + 1 '
+                         'byte slots as they are')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -237,25 +241,63 @@ def main():
     batch = batches[0]
     cells = batch.cells
     res_devs = tx_devs = gathered = gathered_tx = None
+    packed_gather = use_dist and args.gather == 'packed'
     if use_dist:
         res_devs = [torch.as_tensor(b.results_device(), device=dev) for b in batches]
-        tx_devs = [torch.as_tensor(b.transcripts_device(), device=dev) for b in batches]
         tx_sizes = [D.exchange_sizes(b.transcripts_bytes, rank, world, device=dev) for b in batches]
         if rank == 0:
             gathered = [[torch.empty(32 * n_local, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(nfl)]
-            gathered_tx = [[torch.empty(tx_sizes[j][r], dtype=torch.uint8, device=dev) for r in range(world)] for j in range(nfl)]
+        if packed_gather:
+            for b in batches:                                  # (allocates the packed buffer and the offsets)
+                b.pack_transcripts(None); b.sync(None)
+            packed_devs = [torch.as_tensor(b.packed_device()[0], device=dev) for b in batches]
+            # the byte count of a step = the last entry of the offsets the scan writes: 8 bytes on the device ...
+            total_devs = [torch.as_tensor(b.packed_device()[1], device=dev)[8 * n_local:].view(torch.int64) for b in batches]
+            total_pins = [PinnedArray(8, np.uint64) for _ in batches]            # ... and their copy on the host
+            gathered_totals = [[torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)] for _ in range(nfl)] if rank == 0 else None
+            delayed = [D.DelayedRaggedGather(rank, world, tx_sizes[j], device=dev) for j in range(nfl)]
+            moved = []
+        else:
+            tx_devs = [torch.as_tensor(b.transcripts_device(), device=dev) for b in batches]
+            if rank == 0:      # (rank 0 keeps its own slots where they are: no receive buffer for itself)
+                gathered_tx = [[None] + [torch.empty(tx_sizes[j][r], dtype=torch.uint8, device=dev) for r in range(1, world)] for j in range(nfl)]
 
     def step(i):
         j = i % nfl
         with torch.cuda.stream(streams[j]):
             s = streams[j].cuda_stream
+            if packed_gather:
+                # the packed transcripts of this batch's PREVIOUS step leave now: their size has long reached the host,
+                # and the buffers are about to be written again
+                out = delayed[j].collect()
+                if out is not None:
+                    moved.append(sum(int(t.numel()) for t in out[1:]))
             batches[j].solve(s)
             batches[j].traceback(s)
             if use_dist:
-                # the single gather of scores and tracebacks (north star): 32-byte records, then the transcript slots
+                # the single gather of scores and tracebacks (north star): 32-byte records, then the transcripts
                 dist.gather(res_devs[j], gathered[j] if rank == 0 else None, dst=0)
-                D.gather_ragged_wait(D.gather_ragged_start(tx_devs[j], gathered_tx[j] if rank == 0 else None, rank, world))
+                if packed_gather:
+                    batches[j].pack_transcripts(s)
+                    batches[j].packed_total_async(total_pins[j], s)
+                    dist.gather(total_devs[j], gathered_totals[j] if rank == 0 else None, dst=0)
+                    ev = torch.cuda.Event(); ev.record(streams[j])
+
+                    def own_total(ev=ev, pin=total_pins[j]):
+                        ev.synchronize()
+                        return int(pin.array[0])
+                    delayed[j].post(packed_devs[j], own_total, torch.cat(gathered_totals[j]) if rank == 0 else None)
+                else:
+                    D.gather_ragged_wait(D.gather_ragged_start(tx_devs[j], gathered_tx[j] if rank == 0 else None, rank, world))
         return batches[j].cells
+
+    def drain():
+        if packed_gather:
+            for j in range(nfl):
+                with torch.cuda.stream(streams[j]):
+                    out = delayed[j].collect()
+                    if out is not None:
+                        moved.append(sum(int(t.numel()) for t in out[1:]))
 
     def fence():
         if use_dist:
@@ -278,10 +320,13 @@ def main():
         if use_dist:
             dist.all_reduce(need, op=dist.ReduceOp.MAX)
         steps_run = max(args.steps, min(int(need.item()), 100000))
+    drain()
+    fence()
     done_cells = 0
     t0 = time.perf_counter()
     for i in range(steps_run):
         done_cells += step(i)
+    drain()                 # the last steps' transcripts arrive inside the timed region
     fence()
     elapsed = time.perf_counter() - t0
     # fill-kernel duration of the LAST timed step of each batch: with two batches in flight the fills co-run
@@ -332,16 +377,32 @@ def main():
             if r_last > 0:
                 o_l, m_l = synth.pair_batch(batch_seed(r_last, last_j), n_local, LENGTH)
                 rec_l = gathered[last_j][r_last].cpu().numpy().view(RESULT_DTYPE)
-                slots = gathered_tx[last_j][r_last].cpu().numpy()
-                # the slot layout is a function of the lengths alone (pw_batch_tx_slot): cap = X + Y + 1, 16-byte aligned
-                caps = np.array([len(o) + len(m) + 1 for o, m in zip(o_l, m_l)], np.int64)
-                offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16)[:-1]])
-                txs_l = [slots[offs[k] + caps[k] - rec_l['tx_len'][k]: offs[k] + caps[k]].tobytes().decode('ascii')
-                         for k in range(n_local)]
+                if packed_gather:
+                    # the ops back to back in pair order: the offsets are the running sum of the records' lengths
+                    blob = delayed[last_j].last[r_last].cpu().numpy()
+                    offs = np.concatenate([[0], np.cumsum(np.maximum(rec_l['tx_len'], 0))]).astype(np.int64)
+                    gather_ok = gather_ok and int(offs[-1]) == blob.size
+                    txs_l = BatchAligner.transcripts_from_packed(blob, offs)
+                else:
+                    slots = gathered_tx[last_j][r_last].cpu().numpy()
+                    # the slot layout is a function of the lengths alone (pw_batch_tx_slot): cap = X + Y + 1, 16-byte aligned
+                    caps = np.array([len(o) + len(m) + 1 for o, m in zip(o_l, m_l)], np.int64)
+                    offs = np.concatenate([[0], np.cumsum((caps + 15) // 16 * 16)[:-1]])
+                    txs_l = [slots[offs[k] + caps[k] - rec_l['tx_len'][k]: offs[k] + caps[k]].tobytes().decode('ascii')
+                             for k in range(n_local)]
                 gather_ok = gather_ok and verify.check_batch(o_l, m_l, rec_l, txs_l, SCORES['match'], SCORES['mismatch'],
                                                              SCORES['go'], SCORES['ge'], banded=True,
                                                              dmins=[-RADIUS] * n_local) == []
+            if packed_gather:
+                # rank 0's own packed buffer of the last step against its own slots
+                own = delayed[last_j].last[0].cpu().numpy()
+                offs0 = np.concatenate([[0], np.cumsum(np.maximum(results[last_j]['tx_len'], 0))]).astype(np.int64)
+                gather_ok = gather_ok and BatchAligner.transcripts_from_packed(own, offs0) == transcripts[last_j]
             check['gathered_records_and_transcripts_ok'] = gather_ok
+            check['transcript_gather'] = args.gather
+            if packed_gather and moved:
+                check['transcript_bytes_received_per_step'] = int(np.mean(moved))
+                check['transcript_slot_bytes_per_step'] = int(sum(tx_sizes[0][1:]))
     ok = check['rescore_failures'] == 0 and n_ref_bad == 0 and check.get('gathered_records_and_transcripts_ok', True)
 
     # ---- extra legs (outside the timed region) ----------------------------------------------------------------------

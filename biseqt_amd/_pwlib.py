@@ -123,7 +123,8 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_batch_traceback_from', 'pw_batch_sync', 'pw_batch_results_device',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
            'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_table', 'pw_batch_fill_ms',
-           'pw_batch_trace_ms']
+           'pw_batch_trace_ms', 'pw_batch_pack_transcripts', 'pw_batch_packed_device', 'pw_batch_packed_offsets_device',
+           'pw_batch_packed_total_async', 'pw_batch_packed']
 # every symbol include/pw_seeds.h declares
 SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_seeds_is_self', 'pw_seeds_rows_device',
                 'pw_seeds_rows', 'pw_seeds_count', 'pw_seeds_kmers', 'pw_seeds_band_neighbours', 'pw_seeds_graph_build', 'pw_seeds_graph_num_points', 'pw_seeds_graph_points',
@@ -256,6 +257,13 @@ def load():
     lib.pw_batch_fill_ms.restype = C.c_float
     lib.pw_batch_trace_ms.argtypes = [C.c_void_p]
     lib.pw_batch_trace_ms.restype = C.c_float
+    lib.pw_batch_pack_transcripts.argtypes = [C.c_void_p, C.c_void_p]
+    lib.pw_batch_packed_device.argtypes = [C.c_void_p]
+    lib.pw_batch_packed_device.restype = C.c_void_p
+    lib.pw_batch_packed_offsets_device.argtypes = [C.c_void_p]
+    lib.pw_batch_packed_offsets_device.restype = C.c_void_p
+    lib.pw_batch_packed_total_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.pw_batch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     # include/pw_seeds.h
     lib.pw_seeds_create.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                     P(C.c_uint64), C.c_int, C.c_int]

@@ -373,6 +373,38 @@ class BatchAligner(object):
             off[k], cap[k] = o.value, c.value
         return off, cap
 
+    # ---- compacted transcripts (what a gather should move) ----
+    def pack_transcripts(self, stream=None):
+        """After a traceback on ``stream``: the ops of all pairs back to back in pair order and their exclusive offsets
+        (uint64[n + 1]), device-resident (``pw_batch_pack_transcripts``).  Asynchronous on ``stream``."""
+        self._ck(self.lib.pw_batch_pack_transcripts(self.handle, stream), 'pw_batch_pack_transcripts')
+
+    def packed_device(self):
+        """(packed bytes, offsets) as :class:`DeviceBuffer` views; the packed view spans the whole buffer (its first
+        ``offsets[n]`` bytes are the ops)."""
+        return (DeviceBuffer(self.lib.pw_batch_packed_device(self.handle), max(self.transcripts_bytes, 16), self),
+                DeviceBuffer(self.lib.pw_batch_packed_offsets_device(self.handle), 8 * (self.n + 1), self))
+
+    def packed_total_async(self, pinned, stream=None):
+        """D2H of the total number of packed bytes into a :class:`PinnedArray` of 8 bytes, ordered on ``stream``."""
+        self._ck(self.lib.pw_batch_packed_total_async(self.handle, pinned.ptr, stream), 'pw_batch_packed_total_async')
+
+    def packed(self):
+        """(bytes uint8[total], offsets uint64[n + 1]) on the host (synchronous)."""
+        off = np.zeros(self.n + 1, np.uint64)
+        self._ck(self.lib.pw_batch_packed(self.handle, None, 0, off.ctypes.data), 'pw_batch_packed')
+        buf = np.zeros(max(int(off[-1]), 1), np.uint8)
+        self._ck(self.lib.pw_batch_packed(self.handle, buf.ctypes.data, buf.nbytes, None), 'pw_batch_packed')
+        return buf[:int(off[-1])], off
+
+    @staticmethod
+    def transcripts_from_packed(buf, offsets):
+        """List of transcript strings (None for pairs without one) from a packed buffer and its offsets."""
+        offsets = np.asarray(offsets, np.int64)
+        raw = np.asarray(buf, np.uint8).tobytes()
+        return [raw[offsets[k]:offsets[k + 1]].decode('ascii') if offsets[k + 1] > offsets[k] else None
+                for k in range(len(offsets) - 1)]
+
     def scores_plane(self, k):
         """Score of every cell of pair k as ``plane[d - dmin, a]`` (needs PW_FLAG_DUMP_SCORES)."""
         X, Y = self.lens[k]

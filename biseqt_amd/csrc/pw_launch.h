@@ -51,6 +51,9 @@ hipError_t launch_tile(const FillParams<double>& a, int variant, int pair, int n
 hipError_t launch_tile_finish(const FillParams<int32_t>& a, int pair, hipStream_t st);
 hipError_t launch_tile_finish(const FillParams<double>& a, int pair, hipStream_t st);
 hipError_t launch_trace(const TraceParams& p, hipStream_t st);
+// compaction of the transcripts: offsets[n + 1] = exclusive prefix sum of tx_len, packed = the ops back to back
+hipError_t launch_tx_pack(const PairDesc* pairs, const Result* results, const uint8_t* slots, int n, uint64_t* offsets,
+                          uint8_t* packed, hipStream_t st);
 // strip pipeline (pw_strip.h / pw_strip.hip): one standard-mode pair wider than a workgroup
 struct StripParams;
 struct StripTraceParams;

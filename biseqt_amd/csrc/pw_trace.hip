@@ -73,6 +73,64 @@ __global__ __launch_bounds__(64) void k_trace_fixup(const TraceParams p) {
   }
 }
 
+// ---- compaction of the transcripts (the bytes a multi-GPU gather moves) ---------------------------------------------
+// The slots are X + Y + 1 bytes per pair, the ops themselves about half of that.  k_tx_offsets: exclusive prefix sum of
+// tx_len over the pairs (one workgroup: a chunk per thread, the chunk sums scanned in LDS), offsets[n] = total bytes.
+// k_tx_pack: one wavefront per pair copies its ops (right-aligned in the slot) to packed + offsets[pair].
+__global__ __launch_bounds__(1024) void k_tx_offsets(const Result* __restrict__ results, int n, unsigned long long* __restrict__ offsets) {
+  __shared__ unsigned long long part[1024];
+  const int t = (int)threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int k0 = t * per, k1 = k0 + per < n ? k0 + per : n;
+  unsigned long long s = 0;
+  for (int k = k0; k < k1; k++) { const int len = results[k].tx_len; s += len > 0 ? (unsigned long long)len : 0ull; }
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {              // inclusive scan of the chunk sums
+    const unsigned long long v = t >= off ? part[t - off] : 0ull;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  unsigned long long run = t > 0 ? part[t - 1] : 0ull;
+  for (int k = k0; k < k1; k++) {
+    offsets[k] = run;
+    const int len = results[k].tx_len;
+    run += len > 0 ? (unsigned long long)len : 0ull;
+  }
+  if (t == 1023) offsets[n] = part[1023];
+}
+__global__ __launch_bounds__(64) void k_tx_pack(const PairDesc* __restrict__ pairs, const Result* __restrict__ results,
+                                                const uint8_t* __restrict__ slots, const unsigned long long* __restrict__ offsets,
+                                                uint8_t* __restrict__ packed) {
+  const int pair = (int)blockIdx.x;
+  const int len = results[pair].tx_len;
+  if (len <= 0) return;
+  const PairDesc& pd = pairs[pair];
+  const uint8_t* src = slots + pd.tx_off + pd.tx_cap - len;
+  uint8_t* dst = packed + offsets[pair];
+  const int lane = (int)threadIdx.x;
+  // bytes up to the destination's first aligned dword, then dwords (the source read byte-wise: its alignment is another), then the tail
+  const int head = (int)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u);
+  if (lane < head && lane < len) dst[lane] = src[lane];
+  const int nwords = len > head ? (len - head) >> 2 : 0;
+  for (int q = lane; q < nwords; q += 64) {
+    const uint8_t* sp = src + head + 4 * q;
+    PackedU32 v = *(const PackedU32*)sp;
+    *(uint32_t*)(dst + head + 4 * q) = v.v;
+  }
+  const int tail0 = head + 4 * nwords;
+  if (tail0 + lane < len) dst[tail0 + lane] = src[tail0 + lane];
+}
+hipError_t launch_tx_pack(const PairDesc* pairs, const Result* results, const uint8_t* slots, int n, uint64_t* offsets,
+                          uint8_t* packed, hipStream_t st) {
+  hipLaunchKernelGGL(k_tx_offsets, dim3(1), dim3(1024), 0, st, results, n, (unsigned long long*)offsets);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || n <= 0) return e;
+  hipLaunchKernelGGL(k_tx_pack, dim3((unsigned)n), dim3(64), 0, st, pairs, results, slots, (const unsigned long long*)offsets, packed);
+  return hipGetLastError();
+}
+
 // Standard-mode score plane [d - dmin][a] -> the reference's row-major table [x][y] as doubles (what the drop-in
 // materialises for Aligner.table_scores, pw.py:278-285): coalesced writes, the strided reads stay on the device.
 template <typename T>

@@ -557,6 +557,7 @@ struct WaveFill {
 // 16-byte group of the mask plane; an 8-byte store at any byte address
 struct __attribute__((aligned(8))) U4 { uint32_t x, y, z, w; };
 struct __attribute__((packed)) PackedU64 { uint64_t v; };   // an 8-byte store at any byte address
+struct __attribute__((packed)) PackedU32 { uint32_t v; };   // a 4-byte load at any byte address
 
 namespace pk {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -179,6 +179,8 @@ struct pw_batch {
   uint8_t* d_tx = nullptr; uint64_t tx_bytes = 0; size_t tx_alloc = 0;
   void* d_subst = nullptr;
   int32_t* d_ends = nullptr;
+  uint8_t* d_txpacked = nullptr; size_t txpacked_alloc = 0;    // pw_batch_pack_transcripts: the ops back to back
+  uint64_t* d_txoffsets = nullptr;                              // [n + 1]
   hipEvent_t ev_fill0 = nullptr, ev_fill1 = nullptr, ev_tr0 = nullptr, ev_tr1 = nullptr;
   bool fill_timed = false, trace_timed = false;
   // scores as the caller gave them (batch_build may scale b->subst / go / ge by a power of two)
@@ -209,6 +211,8 @@ int batch_free_device(pw_batch* b) {
   pool_give(b->device, b->d_tx, b->tx_alloc);
   if (b->d_subst) (void)hipFree(b->d_subst);
   if (b->d_ends) (void)hipFree(b->d_ends);
+  pool_give(b->device, b->d_txpacked, b->txpacked_alloc);
+  if (b->d_txoffsets) (void)hipFree(b->d_txoffsets);
   if (b->d_waves) (void)hipFree(b->d_waves);
   pool_give(b->device, b->d_fifo, b->fifo_alloc);
   if (b->d_sbest) (void)hipFree(b->d_sbest);
@@ -1043,6 +1047,36 @@ int pw_batch_results(pw_batch* b, pw_result* out) {
 int pw_batch_transcripts(pw_batch* b, uint8_t* out) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->tx_bytes) HIP_TRY(hipMemcpy(out, b->d_tx, b->tx_bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int pw_batch_pack_transcripts(pw_batch* b, void* stream) {
+  HIP_TRY(hipSetDevice(b->device));
+  if (!b->d_txoffsets) {
+    HIP_TRY(pool_alloc(b->device, (void**)&b->d_txpacked, std::max<uint64_t>(b->tx_bytes, 16), &b->txpacked_alloc));
+    HIP_TRY(hipMalloc((void**)&b->d_txoffsets, 8 * ((size_t)b->n + 1)));
+  }
+  HIP_TRY(pw::launch_tx_pack(b->d_pairs, b->d_results, b->d_tx, b->n, b->d_txoffsets, b->d_txpacked, (hipStream_t)stream));
+  return 0;
+}
+void* pw_batch_packed_device(pw_batch* b) { return b->d_txpacked; }
+void* pw_batch_packed_offsets_device(pw_batch* b) { return b->d_txoffsets; }
+int pw_batch_packed_total_async(pw_batch* b, uint64_t* host_out, void* stream) {
+  if (!b->d_txoffsets) return fail("pw_batch_packed_total_async before pw_batch_pack_transcripts");
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpyAsync(host_out, b->d_txoffsets + b->n, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+int pw_batch_packed(pw_batch* b, uint8_t* out, uint64_t cap, uint64_t* offsets_out) {
+  if (!b->d_txoffsets) return fail("pw_batch_packed before pw_batch_pack_transcripts");
+  HIP_TRY(hipSetDevice(b->device));
+  std::vector<uint64_t> off((size_t)b->n + 1);
+  HIP_TRY(hipMemcpy(off.data(), b->d_txoffsets, 8 * off.size(), hipMemcpyDeviceToHost));
+  if (offsets_out) memcpy(offsets_out, off.data(), 8 * off.size());
+  if (out) {
+    if (off[b->n] > cap) return fail("packed transcripts: buffer too small");
+    if (off[b->n]) HIP_TRY(hipMemcpy(out, b->d_txpacked, off[b->n], hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 

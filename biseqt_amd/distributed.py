@@ -132,6 +132,64 @@ def gather_ragged_wait(reqs):
         r.wait()
 
 
+class DelayedRaggedGather(object):
+    """Gather of one ragged uint8 payload per rank and step to rank 0 when the payload's SIZE is only known on the device
+    at the time the step is issued -- the packed transcripts (``pw_batch_pack_transcripts``): their byte count is the last
+    entry of an exclusive scan the GPU has not run yet.  Waiting for it would put a host synchronisation into every step,
+    so the payload travels one use of its slot later, when the size has long arrived on the host:
+
+      step i, slot j (``post``):     the fixed-size traffic of the step goes out as usual -- result records, and the 8-byte
+                                     byte count of every rank (a plain ``gather`` the caller issues: ``totals_gathered``);
+                                     the payload and a way to read its size on the host are remembered
+      next use of slot j, or drain   (``collect``): the sender reads its own count (an 8-byte D2H the stream finished long
+                                     ago), the root reads the gathered counts (one small D2H), and ONE grouped send / receive
+                                     moves exactly the bytes that exist -- no padding, each rank over its direct link to the root
+
+    ``caps[r]`` is the largest payload rank r can ever send (the slot bytes); rank 0 allocates its receive buffers once."""
+
+    def __init__(self, rank, world, caps, device=None, group=None):
+        import torch
+        self.rank, self.world, self.group = rank, world, group
+        self.recv = None
+        if rank == 0 and world > 1:
+            self.recv = [None] + [torch.empty(max(int(caps[r]), 1), dtype=torch.uint8, device=device) for r in range(1, world)]
+        self.pending = None
+        self.last = None
+
+    def post(self, payload, own_total, totals_gathered=None):
+        """``payload``: uint8 tensor holding this rank's bytes in its first ``own_total()`` bytes (callable, evaluated at
+        collect time); ``totals_gathered``: on rank 0 the int64 tensor [world] of every rank's count, filled by the
+        fixed-size gather of the same step."""
+        assert self.pending is None, 'collect() the previous step of this slot first'
+        self.pending = (payload, own_total, totals_gathered)
+
+    def collect(self):
+        """Moves the pending payloads; on rank 0 returns the list of per-rank uint8 tensors (rank 0's own first), None on
+        the other ranks and when nothing is pending."""
+        import torch.distributed as dist
+        if self.pending is None:
+            return None
+        payload, own_total, totals = self.pending
+        self.pending = None
+        n_own = int(own_total())
+        if self.world == 1:
+            self.last = [payload[:n_own]]
+            return self.last
+        if self.rank == 0:
+            sizes = [int(v) for v in totals.cpu().tolist()]
+            assert sizes[0] == n_own, (sizes[0], n_own)
+            ops = [dist.P2POp(dist.irecv, self.recv[r][:sizes[r]], r, self.group) for r in range(1, self.world) if sizes[r] > 0]
+        else:
+            ops = [dist.P2POp(dist.isend, payload[:n_own], 0, self.group)] if n_own > 0 else []
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.rank != 0:
+            return None
+        self.last = [payload[:n_own]] + [self.recv[r][:sizes[r]] for r in range(1, self.world)]
+        return self.last
+
+
 def exchange_sizes(n_local, rank, world, device=None, group=None):
     """Every rank's byte count, as a list of ints on every rank (once, at set-up time)."""
     import torch

@@ -132,6 +132,16 @@ int pw_batch_tx_slot(const pw_batch* b, int32_t k, uint64_t* off, int32_t* cap);
  * returned only if the second solve fails as well. */
 int pw_batch_results(pw_batch* b, pw_result* host_out);
 int pw_batch_transcripts(pw_batch* b, uint8_t* host_out);                        /* synchronous D2H of all slots */
+/* Compaction (what a multi-GPU gather should move: the slots are X + Y + 1 bytes per pair, the ops about half of that).
+ * After a traceback on `stream`: the ops of all pairs back to back in pair order, no padding, and their exclusive offsets
+ * (uint64[n_pairs + 1]; [n_pairs] = total bytes), both device-resident; asynchronous on `stream`.  Pairs without a
+ * transcript take no bytes.  pw_batch_packed: synchronous D2H of offsets (n_pairs + 1) and / or bytes (either may be NULL);
+ * pw_batch_packed_total_async: D2H of the total alone (8 bytes, into pinned memory), ordered on `stream`. */
+int pw_batch_pack_transcripts(pw_batch* b, void* stream);
+void* pw_batch_packed_device(pw_batch* b);
+void* pw_batch_packed_offsets_device(pw_batch* b);
+int pw_batch_packed_total_async(pw_batch* b, uint64_t* host_out, void* stream);
+int pw_batch_packed(pw_batch* b, uint8_t* host_out, uint64_t cap, uint64_t* offsets_out);
 /* score plane of pair k (PW_FLAG_DUMP_SCORES): out[(d-dmin)*pitch + a], pitch = min(X,Y)+1, as doubles */
 int pw_batch_scores(pw_batch* b, int32_t k, double* host_out, int64_t n);
 /* Standard mode only: the same scores as the reference's table, host_out[x * (Y + 1) + y] for 0 <= x <= X,

@@ -9,8 +9,10 @@ export TMPDIR=/tmp
 O=$R/gpurun_out/profb
 rm -rf $O; mkdir -p $O
 cd /tmp
+# (--no-extras: only the timed loop and the serial leg run, one batch in flight, so EVERY launch of the fill kernel in this
+#  trace runs alone -- its --stats average is the figure roofline.kernel_ms reports; the e2e leg keeps three batches in flight)
 echo "stats, --inflight 1"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/inflight1 -- python3 $R/bench.py --inflight 1 --steps 10 --warmup 3 --min-seconds 0 > $O/bench_inflight1.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/inflight1 -- python3 $R/bench.py --inflight 1 --steps 10 --warmup 3 --min-seconds 0 --no-extras > $O/bench_inflight1.log 2>&1
 echo "stats, default"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/default -- python3 $R/bench.py > $O/bench_default.log 2>&1
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "WRITE_SIZE" "FETCH_SIZE"; do

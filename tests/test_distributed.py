@@ -154,3 +154,56 @@ def test_bench_self_launch_refuses_without_enough_devices():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
     assert p.returncode == 2
     assert 'needs %d visible devices' % want in p.stderr
+
+
+def _worker_delayed(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    from biseqt_amd import distributed as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cap = 5000
+    caps = [cap] * world
+    nfl = 2                                                   # two slots in flight, as bench.py keeps two batches
+    slots = [D.DelayedRaggedGather(rank, world, caps) for _ in range(nfl)]
+    bufs = [torch.zeros(cap, dtype=torch.uint8) for _ in range(nfl)]
+    def size_of(step, r):
+        return 0 if (step == 2 and r == 1) else 700 + 131 * step + 17 * r      # data dependent, one empty payload
+
+    def content(step, r, n):
+        return ((np.arange(n) * (r + 3) + step) % 251).astype(np.uint8)
+
+    for step in range(5):
+        j = step % nfl
+        out = slots[j].collect()                              # the payload of this slot's previous step, if any
+        if out is not None and rank == 0:                     # (checked before the slot's buffer is written again: rank 0's
+            for r in range(world):                            #  own part is a view of it) -- it belongs to step - nfl
+                exp = content(step - nfl, r, size_of(step - nfl, r))
+                assert out[r].numel() == len(exp) and (out[r].numpy() == exp).all(), (step, r)
+        n = size_of(step, rank)
+        bufs[j][:n] = torch.from_numpy(content(step, rank, n))
+        mine = torch.tensor([n], dtype=torch.int64)
+        totals = [torch.zeros(1, dtype=torch.int64) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, totals, dst=0)                      # the step's fixed-size traffic carries the byte counts
+        slots[j].post(bufs[j], (lambda n=n: n), torch.cat(totals) if rank == 0 else None)
+    for j in range(nfl):                                      # drain
+        out = slots[j].collect()
+        if rank == 0:
+            s = [st for st in (3, 4) if st % nfl == j][0]
+            for r in range(world):
+                exp = content(s, r, size_of(s, r))
+                assert out[r].numel() == len(exp) and (out[r].numpy() == exp).all(), (s, r)
+    assert all(sl.collect() is None for sl in slots)
+    if rank == 0:
+        open(os.path.join(outdir, 'ok'), 'w').write('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_delayed_gather_of_packed_transcripts(tmp_path):
+    """bench.py's gather of the PACKED transcripts: byte counts are data dependent and known on the device only, so they
+    ride with the step's fixed-size gather and the bytes follow one use of the slot later (DelayedRaggedGather)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_delayed, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'ok'))

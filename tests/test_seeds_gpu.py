@@ -178,7 +178,7 @@ def test_gpu_seeds_equal_the_reference_seed_lists(A):
     (`WordBlotOverlapRef.seeds` / `seed_count`, blot.py:607-642; tests/golden/seed_lists_reference.json.gz, generated by
     importing the reference): the in-memory class row for row in its (j, i) order, `SeedIndex` as the same set."""
     import hashlib
-    from biseqt_amd.blot import WordBlotOverlapRef
+    from biseqt_amd.blot import WordBlotLocalRef, WordBlotOverlapRef
     from biseqt_amd.seeds import SeedIndex
     from tests.helpers import dec, load_golden
     recs = load_golden('seed_lists_reference.json.gz')
@@ -188,7 +188,10 @@ def test_gpu_seeds_equal_the_reference_seed_lists(A):
         if len(S) < w or len(T) < w:
             assert rec['seeds_ij_n'] == 0                   # (sequences shorter than the word: no k-mers at all)
             continue
-        WB = WordBlotOverlapRef(_seq(A, S), wordlen=w, alphabet=A, g_max=0.2, sensitivity=0.9)
+        # (the product's overlap class refuses self comparisons -- DESIGN.md section 9; its local-similarity sibling shares
+        #  the enumeration and takes them)
+        cls = WordBlotLocalRef if S == T else WordBlotOverlapRef
+        WB = cls(_seq(A, S), wordlen=w, alphabet=A, g_max=0.2, sensitivity=0.9)
         WB._set_query(_seq(A, T))
         rows = [(int(i), int(j)) for i, j in WB.seeds()]
         assert len(rows) == rec['seeds_ij_n'], k
