@@ -37,7 +37,8 @@ def extend_segments(S, T, segments, wordlen, device=0, **aligner_kw):
     ``WordBlot.similar_segments`` yields them) in one GPU batch.  ``aligner_kw`` are ``Aligner`` keywords
     (``alnmode`` / ``alntype`` default to banded global as in the reference's experiment; ``diag_range`` is set
     per segment).  Returns one dict per segment: ``frame``, ``diag_range``, ``score``, ``alignment`` (an
-    :class:`Alignment` on the frame sequences, or None) and ``truncated`` (``alignment.truncate_to_match()``)."""
+    :class:`Alignment` on the frame sequences, or None), ``truncated`` (``alignment.truncate_to_match()``) and ``kernel``
+    (the batch's fill kernel and score type, for diagnostics)."""
     assert isinstance(S, Sequence) and isinstance(T, Sequence)
     kw = dict(alnmode=W.BANDED_MODE, alntype=W.B_GLOBAL)
     kw.update(aligner_kw)
@@ -55,9 +56,10 @@ def extend_segments(S, T, segments, wordlen, device=0, **aligner_kw):
     with BatchAligner(pairs, alphabet_len=len(S.alphabet), diag_range=bands, device=device, **kw) as b:
         res = b.run()
         txs = b.transcripts(res)
+        kernel = (b.kernel_name, b.score_dtype)
     out = []
     for k, (fi, fj) in enumerate(frames):
-        rec = {'frame': (fi, fj), 'diag_range': bands[k], 'score': None, 'alignment': None, 'truncated': None}
+        rec = {'frame': (fi, fj), 'diag_range': bands[k], 'score': None, 'alignment': None, 'truncated': None, 'kernel': kernel}
         if res['opt_i'][k] >= 0 and txs[k]:
             rec['score'] = float(res['score'][k])
             aln = Alignment(S[fi[0]:fi[1]], T[fj[0]:fj[1]], txs[k], score=rec['score'],

@@ -64,3 +64,65 @@ def check_batch(origins, mutants, results, transcripts, match, mismatch, go, ge,
         if not ok or s != r['score'] or (ex, ey) != exy:
             bad.append(k)
     return bad
+
+
+# ---- many alignments at once: packed transcripts, reads in one arena, several host processes ---------------------------
+def _check_packed_range(args):
+    """Worker of :func:`check_packed_parallel`: pairs [k0, k1) of a batch whose reads live in a shared-memory arena and
+    whose transcripts are packed back to back in another.  Returns (checked, list of bad pair indices)."""
+    from multiprocessing import shared_memory
+    (arena_name, arena_n, tx_name, tx_n, k0, k1, roff, rlen, pidx, rec, off, lo, hi, scores, overlap) = args
+    sa, st = shared_memory.SharedMemory(name=arena_name), shared_memory.SharedMemory(name=tx_name)
+    try:
+        arena = np.ndarray((arena_n,), np.uint8, buffer=sa.buf)
+        txb = np.ndarray((tx_n,), np.uint8, buffer=st.buf)
+        match, mismatch, go, ge = scores
+        bad, checked = [], 0
+        for k in range(k0, k1):
+            r = rec[k - k0]
+            if r['opt_i'] < 0 or (r['status'] & 6) or r['tx_len'] <= 0:
+                bad.append(k)                                   # (every pair of such a job has an alignment)
+                continue
+            a, c = pidx[k - k0]
+            o = arena[roff[a]:roff[a] + rlen[a]]
+            m = arena[roff[c]:roff[c] + rlen[c]]
+            ops = txb[off[k - k0]:off[k - k0 + 1]]
+            x0, y0 = int(r['origin_idx']), int(r['mutant_idx'])
+            s, ex, ey, ok = rescore(o, m, ops, x0, y0, match, mismatch, go, ge)
+            exy = end_cell_xy(r['opt_i'], r['opt_j'], True, lo[k - k0])
+            good = ok and s == r['score'] and (ex, ey) == exy
+            if good and overlap:
+                # an overlap alignment starts on the table edge and ends on the last row or column, inside its band
+                d = x0 - y0 + np.cumsum((ops == 68).astype(np.int64) - (ops == 73).astype(np.int64))
+                good = (x0 == 0 or y0 == 0) and (ex == len(o) or ey == len(m)) and \
+                    lo[k - k0] <= min(int(d.min()), x0 - y0) and max(int(d.max()), x0 - y0) <= hi[k - k0]
+            if not good:
+                bad.append(k)
+            checked += 1
+        return checked, bad
+    finally:
+        sa.close(); st.close()
+
+
+def check_packed_parallel(pool, arena_shm, arena_n, roff, rlen, pidx, records, packed, offsets, lo, hi, scores, overlap=True,
+                          chunk=4000):
+    """Re-scores every alignment of a batch on the host cores (``pool``: a multiprocessing pool of spawned workers): the reads
+    sit in the shared-memory block ``arena_shm`` (read ``a`` at ``roff[a]``, ``rlen[a]`` letters), the batch's transcripts come
+    packed (``BatchAligner.packed``).  Returns (checked, bad indices)."""
+    from multiprocessing import shared_memory
+    n = len(pidx)
+    st = shared_memory.SharedMemory(create=True, size=max(int(len(packed)), 1))
+    try:
+        np.ndarray((len(packed),), np.uint8, buffer=st.buf)[:] = packed
+        jobs = []
+        for k0 in range(0, n, chunk):
+            k1 = min(n, k0 + chunk)
+            jobs.append((arena_shm.name, arena_n, st.name, len(packed), k0, k1, roff, rlen, pidx[k0:k1], records[k0:k1],
+                         np.asarray(offsets[k0:k1 + 1], np.int64), np.asarray(lo[k0:k1]), np.asarray(hi[k0:k1]), scores, overlap))
+        checked, bad = 0, []
+        for c, b in pool.imap_unordered(_check_packed_range, jobs):
+            checked += c
+            bad += b
+        return checked, sorted(bad)
+    finally:
+        st.close(); st.unlink()
