@@ -124,7 +124,7 @@ EXPORTS = ['dptable_init', 'dptable_solve', 'dptable_traceback', 'dptable_free',
            'pw_batch_transcripts_device', 'pw_batch_transcripts_bytes', 'pw_batch_tx_slot',
            'pw_batch_results', 'pw_batch_transcripts', 'pw_batch_scores', 'pw_batch_table', 'pw_batch_fill_ms',
            'pw_batch_trace_ms', 'pw_batch_pack_transcripts', 'pw_batch_packed_device', 'pw_batch_packed_offsets_device',
-           'pw_batch_packed_total_async', 'pw_batch_packed']
+           'pw_batch_packed_total_async', 'pw_batch_packed', 'pw_plan_only']
 # every symbol include/pw_seeds.h declares
 SEED_EXPORTS = ['pw_seeds_create', 'pw_seeds_build', 'pw_seeds_num_rows', 'pw_seeds_is_self', 'pw_seeds_rows_device',
                 'pw_seeds_rows', 'pw_seeds_count', 'pw_seeds_kmers', 'pw_seeds_band_neighbours', 'pw_seeds_graph_build', 'pw_seeds_graph_num_points', 'pw_seeds_graph_points',
@@ -264,6 +264,7 @@ def load():
     lib.pw_batch_packed_offsets_device.restype = C.c_void_p
     lib.pw_batch_packed_total_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.pw_batch_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.pw_plan_only.argtypes = [P(pw_scoring), C.c_int32, P(pw_pair), C.c_uint64, C.c_uint32, C.c_char_p, C.c_int32, P(C.c_int32)]
     # include/pw_seeds.h
     lib.pw_seeds_create.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                     P(C.c_uint64), C.c_int, C.c_int]

@@ -82,7 +82,7 @@ def _jobs():
                  [os.path.join(HERE, 'pw_overlap.hip'), os.path.join(ROOT, 'include', 'pw_overlap.h')]))
     obj = os.path.join(OBJ_DIR, 'pwlib_api.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-x', 'hip', '-c', os.path.join(HERE, 'pwlib_api.cpp'), '-o', obj],
-                 [os.path.join(HERE, 'pwlib_api.cpp'), os.path.join(ROOT, 'include', 'pwlib.h'),
+                 [os.path.join(HERE, 'pwlib_api.cpp'), os.path.join(HERE, 'pw_model.h'), os.path.join(ROOT, 'include', 'pwlib.h'),
                   os.path.join(ROOT, 'include', 'pw_batch.h')]))
     return jobs
 

@@ -21,6 +21,7 @@
 #include "../../include/pw_batch.h"
 #include "pw_launch.h"
 #include "pw_plan.h"
+#include "pw_model.h"
 #define PW_FN inline
 #include "pw_strip.h"
 #include <atomic>
@@ -47,7 +48,9 @@ size_t g_pool_held[kMaxDevices] = {0};     // bytes parked per device
 size_t g_pool_cap[kMaxDevices] = {0};      // 0 = not computed yet
 
 // Cap of the bytes parked on one device: PWLIB_POOL_GB if set (0 disables the pool), otherwise a quarter of the
-// device's memory (72 GB on an MI355X), read once per device.
+// device's memory (72 GB on an MI355X), read once per device -- and, at the moment a buffer is parked, never more than
+// half of what is FREE on the device then (parked bytes included): several processes sharing a device, or another
+// allocator in this process (torch, RCCL), then see the pool shrink instead of an out-of-memory error.
 size_t pool_cap(int device) {
   if (device < 0 || device >= kMaxDevices) return 0;
   if (g_pool_cap[device] == 0) {
@@ -61,6 +64,15 @@ size_t pool_cap(int device) {
     g_pool_cap[device] = cap + 1;            // + 1: "computed" even when the cap itself is 0
   }
   return g_pool_cap[device] - 1;
+}
+// ... the free-memory half of the rule (the caller holds no lock; the device is current)
+size_t pool_room_now(int device, size_t held) {
+  static const bool fixed = [] { const char* v = getenv("PWLIB_POOL_GB"); return v && *v; }();
+  const size_t cap = pool_cap(device);
+  if (fixed) return cap;
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) return cap;
+  return std::min(cap, (fr + held) / 2);
 }
 
 void* pool_take(int device, size_t bytes, size_t* got) {
@@ -80,7 +92,9 @@ void* pool_take(int device, size_t bytes, size_t* got) {
 void pool_give(int device, void* p, size_t bytes) {
   if (!p) return;
   if (device >= 0 && device < kMaxDevices && bytes >= (1u << 20)) {
-    const size_t cap = pool_cap(device);
+    size_t held_now;
+    { std::lock_guard<std::mutex> lk(g_pool_mutex); held_now = g_pool_held[device]; }
+    const size_t cap = pool_room_now(device, held_now);
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     if (g_pool_held[device] + bytes <= cap && g_pool.size() < 64) {
       g_pool.push_back(PoolEntry{p, bytes, device});
@@ -150,6 +164,7 @@ struct pw_batch {
   double go = 0, ge = 0;
   std::vector<double> subst;
   bool simple = false, use_f64 = false;
+  double plan_ms = 0;
   int scale_shift = 0;                   // dyadic scaling: every score is held times 2^scale_shift by the integer kernels
   double score_mul = 1.0;                // 2^-scale_shift: what the kernels multiply a reported score with
   int variant = 0, brule = 0, endrule = 0, gosign = 0;
@@ -188,6 +203,9 @@ struct pw_batch {
   // Strip pairs whose pipeline gave up waiting (PW_ST_BADPATH with no end cell) are solved again by a batch of one with the
   // strips disabled (repair_strip_pair); the replacement lives as long as the batch and serves every later traceback
   std::vector<std::pair<int32_t, pw_batch*>> repaired;
+  // one event per stream the batch was launched on, re-recorded behind every launch sequence: destroying the batch waits
+  // for exactly these (not for the device: other batches' streams keep running)
+  std::vector<std::pair<hipStream_t, hipEvent_t>> done_events;
   bool traced = false, traced_from = false;          // what the last traceback call was (a repaired pair repeats it)
   std::vector<int32_t> last_ends;
 };
@@ -200,8 +218,10 @@ int batch_free_device(pw_batch* b) {
   b->repaired.clear();
   (void)hipSetDevice(b->device);
   // the buffers are parked for the next batch, not freed (hipFree would synchronise by itself): make sure nothing that
-  // was launched on any stream still reads or writes them
-  (void)hipDeviceSynchronize();
+  // was launched for THIS batch still reads or writes them -- the events recorded behind its launches, stream by stream
+  // (a device-wide synchronisation would stall every other batch in flight)
+  for (auto& se : b->done_events) { (void)hipEventSynchronize(se.second); (void)hipEventDestroy(se.second); }
+  b->done_events.clear();
   for (auto& c : b->classes) if (c.d_order) (void)hipFree(c.d_order);
   if (!b->arena_shared) pool_give(b->device, b->d_arena, b->arena_alloc);
   pool_give(b->device, b->d_pairs, b->pairs_alloc);
@@ -228,7 +248,9 @@ int batch_free_device(pw_batch* b) {
 
 bool is_integral(double v) { return v == floor(v) && fabs(v) < 1e9; }
 
-int batch_build(pw_batch* b) {
+// Planning: host arithmetic only (dptable_init per pair, score type, kernel variant and geometry, launch classes) -- no
+// device call, so pw_plan_only can run it anywhere.  batch_alloc then creates the device buffers it sized.
+int batch_plan(pw_batch* b) {
   const double t_build0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   // ---- scoring analysis ----
   const int L = b->L;
@@ -279,18 +301,10 @@ int batch_build(pw_batch* b) {
   b->gosign = b->go < 0 ? -1 : (b->go > 0 ? 1 : 0);
   // ---- pass 1: per-pair plans (dptable_init arithmetic) and batch statistics ----
   int64_t maxspan = 0, maxmin = 0; int maxnd = 0; int64_t sumnd = 0; int nsolv = 0;
-  // standard mode, a batch of few pairs: the strip pipeline solves the pairs one after another (each with the whole chip),
-  // the workgroup-per-pair kernels all of them at once -- estimated times of both (tests/micro/few_pairs.py)
-  double est_strips_ms = 0.0, est_wgroups_ms = 0.0;
-  // one step of a workgroup's pair: 8 wavefronts with 4 / 8 / 16 / 32 diagonals per lane (tests/micro/few_pairs.py)
-  auto wg_us_per_step = [](int ndiag) { return ndiag <= 2048 ? 0.45 : (ndiag <= 4096 ? 0.7 : (ndiag <= 8192 ? 1.3 : 5.5)); };
-  // ... the same for f64 scores (the wide lanes spill kilobytes of registers: 8 kb x 8 kb takes 317 ms), and the time-blocked
-  // tiled kernel, which like the strips takes the pairs one after another (0.43 us per anti-diagonal, whatever the width)
-  auto wg_us_per_step_f64 = [](int ndiag) { return ndiag <= 1024 ? 0.47 : (ndiag <= 2048 ? 0.6 : (ndiag <= 4096 ? 1.0 : (ndiag <= 8192 ? 2.7 : 19.8))); };
-  double est_tiles_ms = 0.0, est_wgroups_int_ms = 0.0, est_wgroups_f64_ms = 0.0;
-  // ... and the 16-bit body on several wavefronts per pair (k_fill16_mw), where the scores admit it
-  auto pmw_us_per_step = [](int ndiag) { return ndiag <= 4096 ? 0.38 : (ndiag <= 8192 ? 0.6 : 1.2); };
-  double est_pmw_ms = 0.0;
+  // a batch of few pairs: kernels that take the pairs one after another (strips, tiles: each pair gets the whole chip)
+  // against kernels that take all of them at once -- estimated times of both from the one table of pw_model.h
+  const pw::PlanModel& model = pw::kPlanModel;
+  pw::BatchEstimates est;
   int min_x = 0x7fffffff;
   b->plans.resize(b->n); b->descs.resize(b->n);
   uint64_t mask_words = 0, h_elems = 0, tx_bytes = 0;
@@ -320,19 +334,9 @@ int batch_build(pw_batch* b) {
       maxspan = std::max<int64_t>(maxspan, (int64_t)p.origin_len + p.mutant_len + 2);
       maxmin = std::max<int64_t>(maxmin, std::min(p.origin_len, p.mutant_len));
       maxnd = std::max(maxnd, pl.ndiag); sumnd += pl.ndiag; nsolv++;
-      {
-        const double steps = (double)pl.nblocks * 16.0;        // anti-diagonals of the (banded) table
-        est_tiles_ms += 0.05 + steps * 0.00043;
-        est_wgroups_int_ms = std::max(est_wgroups_int_ms, steps * wg_us_per_step(pl.ndiag) * 1e-3);
-        est_wgroups_f64_ms = std::max(est_wgroups_f64_ms, steps * wg_us_per_step_f64(pl.ndiag) * 1e-3);
-        est_pmw_ms = std::max(est_pmw_ms, steps * pmw_us_per_step(pl.ndiag) * 1e-3);
-        min_x = std::min(min_x, (int)p.origin_len);
-      }
-      if (b->mode == pw::STD_MODE) {
-        const double X = p.origin_len, Y = p.mutant_len;
-        est_strips_ms += 0.04 + 0.0105 * ceil((X + 1) / 64.0) + 0.000095 * (Y + 64);
-        est_wgroups_ms = std::max(est_wgroups_ms, (X + Y) * wg_us_per_step(pl.ndiag) * 1e-3);
-      }
+      est.add_pair(model, (double)pl.nblocks * 16.0 /* anti-diagonals of the (banded) table */, pl.ndiag);
+      min_x = std::min(min_x, (int)p.origin_len);
+      if (b->mode == pw::STD_MODE) est.add_std_pair(model, p.origin_len, p.mutant_len, pl.ndiag);
     }
     b->descs[k] = d;
   }
@@ -391,7 +395,7 @@ int batch_build(pw_batch* b) {
   //  there; four pairs 2.3 ms and 1.6 ms)
   const bool strips_win = latency_mode && b->simple && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
                           !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) && !(b->flags & PW_FLAG_NO_STRIP) &&
-                          (double)maxspan * maxabs < (double)(1 << 25) && est_strips_ms < 0.9 * est_pmw_ms;
+                          (double)maxspan * maxabs < (double)(1 << 25) && est.strips_beat_packed_workgroups(model);
   if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd > 2048 && maxnd <= 64 * pw::kMaxWavesPerPair * 32 &&
       nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0 && !env_int("PWLIB_NO_PACKED_MW", 0) && !strips_win) {
@@ -472,7 +476,7 @@ int batch_build(pw_batch* b) {
     // strips of all pairs, one pair after another, are estimated to finish before the slowest workgroup would (2 kb x 2 kb:
     // 0.6 ms per pair against 13.6 ms for one workgroup of 32-diagonal lanes -- up to 16 such pairs; 1 kb x 1 kb: 0.3 ms
     // against 1.0 ms -- up to 2), for tables that span at least two strips
-    const bool few = latency_mode && d.X >= 127 && est_strips_ms < 0.9 * est_wgroups_ms;
+    const bool few = latency_mode && d.X >= 127 && est.strips_beat_workgroups(model);
     if (strip_ok && ((b->flags & PW_FLAG_FORCE_STRIP) || d.ndiag > 2048 * pw::kMaxWavesPerPair || (few && !env_int("PWLIB_NO_SMALL_STRIP", 0)))) {
       // one pair wider than a workgroup, integer scores, simple scoring: rows in strips of 64, a pipeline of wavefronts
       const int nstrips = (d.X + 1 + 63) / 64, nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
@@ -487,7 +491,7 @@ int batch_build(pw_batch* b) {
     // a few pairs with bands wider than a wavefront holds, not served by the strips (f64 scores, a substitution matrix,
     // go > 0, banded): the tiled kernel when all pairs, one after another, are estimated to finish before the slowest workgroup
     const bool few_tiled = latency_mode && d.ndiag > 1024 && !(b->flags & PW_FLAG_DUMP_SCORES) && !env_int("PWLIB_NO_SMALL_TILED", 0) &&
-                           est_tiles_ms < 0.9 * (b->use_f64 ? est_wgroups_f64_ms : est_wgroups_int_ms);
+                           est.tiles_beat_workgroups(model, b->use_f64);
     if (b->variant == pw::VAR_FAST16) { bk = pbk; nl = pnl; }
     else if ((b->flags & PW_FLAG_FORCE_TILED) || d.ndiag > 2048 * pw::kMaxWavesPerPair || few_tiled) {
       // wider than a workgroup holds (or forced): time-blocked tiles of the band, one pair after another
@@ -564,13 +568,20 @@ int batch_build(pw_batch* b) {
       b->waves.push_back(wd);
     }
   }
+  b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
+  b->arena_shared = (b->flags & PW_FLAG_SHARED_ARENA) != 0;
+  b->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_build0;
+  return 0;
+}
+
+int batch_alloc(pw_batch* b) {
+  const int L = b->L;
+  const uint64_t mask_words = b->mask_words, h_elems = b->h_elems, tx_bytes = b->tx_bytes;
   // ---- device buffers ----
   const bool tim = env_int("PWLIB_TIMING", 0) != 0;
   auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_plan = tnow();
   HIP_TRY(hipSetDevice(b->device));
-  b->mask_words = mask_words; b->h_elems = h_elems; b->tx_bytes = tx_bytes;
-  b->arena_shared = (b->flags & PW_FLAG_SHARED_ARENA) != 0;
   if (!b->arena_shared)
     HIP_TRY(pool_alloc(b->device, (void**)&b->d_arena, b->arena_bytes + 16, &b->arena_alloc));   // kernels read whole dwords: slack past the last frame
   HIP_TRY(pool_alloc(b->device, (void**)&b->d_pairs, sizeof(pw::PairDesc) * std::max<int32_t>(b->n, 1), &b->pairs_alloc));
@@ -618,7 +629,23 @@ int batch_build(pw_batch* b) {
     HIP_TRY(hipEventCreate(&b->ev_fill0)); HIP_TRY(hipEventCreate(&b->ev_fill1));
     HIP_TRY(hipEventCreate(&b->ev_tr0)); HIP_TRY(hipEventCreate(&b->ev_tr1));
   }
-  if (tim && b->n > 1000) fprintf(stderr, "pwlib timing: batch of %d pairs: planning %.1f ms, device buffers + descriptors %.1f ms\n", b->n, t_plan - t_build0, tnow() - t_plan);
+  if (tim && b->n > 1000) fprintf(stderr, "pwlib timing: batch of %d pairs: planning %.1f ms, device buffers + descriptors %.1f ms\n", b->n, b->plan_ms, tnow() - t_plan);
+  return 0;
+}
+
+int batch_build(pw_batch* b) {
+  if (batch_plan(b) != 0) return -1;
+  return batch_alloc(b);
+}
+
+// Records "everything launched for this batch on `st` so far" (see pw_batch::done_events).
+int mark_done(pw_batch* b, hipStream_t st) {
+  for (auto& se : b->done_events)
+    if (se.first == st) { HIP_TRY(hipEventRecord(se.second, st)); return 0; }
+  hipEvent_t ev = nullptr;
+  HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  b->done_events.emplace_back(st, ev);
+  HIP_TRY(hipEventRecord(ev, st));
   return 0;
 }
 
@@ -804,6 +831,30 @@ void pw_batch_destroy(pw_batch* b) {
   delete b;
 }
 
+int pw_plan_only(const pw_scoring* sc, int32_t n_pairs, const pw_pair* pairs, uint64_t arena_bytes, uint32_t flags,
+                 char* kernel, int32_t kernel_cap, int32_t* info) {
+  if (!sc || n_pairs < 0 || (n_pairs > 0 && !pairs) || !sc->subst) return fail("pw_plan_only: bad arguments");
+  if (sc->mode != pw::STD_MODE && sc->mode != pw::BANDED_MODE) return fail("unknown alignment mode");
+  if (sc->type < 0 || sc->type > (sc->mode == pw::STD_MODE ? 6 : 2)) return fail("unknown alignment type");
+  if (sc->alphabet_len < 1 || sc->alphabet_len > 256) return fail("alphabet_len must be 1..256 with a score matrix");
+  pw_batch b;
+  b.device = -1; b.n = n_pairs; b.flags = flags;
+  b.mode = sc->mode; b.type = sc->type; b.L = sc->alphabet_len; b.go = sc->go; b.ge = sc->ge;
+  b.subst.assign(sc->subst, sc->subst + (size_t)b.L * b.L);
+  b.pairs.assign(pairs, pairs + n_pairs);
+  b.arena_bytes = arena_bytes;
+  if (batch_plan(&b) != 0) return -1;
+  if (kernel && kernel_cap > 0) { strncpy(kernel, pw_batch_kernel_name(&b), (size_t)kernel_cap - 1); kernel[kernel_cap - 1] = 0; }
+  if (info) {
+    int64_t one = 0, wg = 0;
+    for (const auto& c : b.classes) (c.nw > 1 || (b.variant == pw::VAR_FAST16 && b.packed_nw > 1) ? wg : one) += (int64_t)c.order.size();
+    info[0] = b.use_f64 ? 1 : 0; info[1] = b.scale_shift; info[2] = (int32_t)one; info[3] = (int32_t)wg;
+    info[4] = (int32_t)b.tiled.size(); info[5] = (int32_t)b.strips.size();
+    info[6] = b.variant == pw::VAR_FAST16 ? b.packed_rule : -1; info[7] = b.packed_mat;
+  }
+  return 0;
+}
+
 int pw_batch_init_rc(const pw_batch* b, int32_t k) { return (k < 0 || k >= b->n) ? -1 : b->plans[k].rc; }
 
 int pw_batch_band(const pw_batch* b, int32_t k, int32_t* dmin, int32_t* dmax, int32_t* num_rows) {
@@ -884,17 +935,17 @@ int pw_batch_upload_arena_async(pw_batch* b, const uint8_t* host, uint64_t bytes
   if (bytes > b->arena_bytes) return fail("arena upload larger than the arena");
   HIP_TRY(hipSetDevice(b->device));
   if (bytes) HIP_TRY(hipMemcpyAsync(b->d_arena, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-  return 0;
+  return mark_done(b, (hipStream_t)stream);
 }
 int pw_batch_results_async(pw_batch* b, pw_result* out, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->n) HIP_TRY(hipMemcpyAsync(out, b->d_results, sizeof(pw_result) * (size_t)b->n, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  return 0;
+  return mark_done(b, (hipStream_t)stream);
 }
 int pw_batch_transcripts_async(pw_batch* b, uint8_t* out, void* stream) {
   HIP_TRY(hipSetDevice(b->device));
   if (b->tx_bytes) HIP_TRY(hipMemcpyAsync(out, b->d_tx, b->tx_bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  return 0;
+  return mark_done(b, (hipStream_t)stream);
 }
 
 int pw_batch_solve(pw_batch* b, void* stream) {
@@ -913,7 +964,7 @@ int pw_batch_solve(pw_batch* b, void* stream) {
   if (rc == 0 && !b->strips.empty()) rc = launch_strip_fills(b, st);
   if (rc != 0) return rc;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_fill1, st)); b->fill_timed = true; }
-  return 0;
+  return mark_done(b, st);
 }
 
 static pw_batch* repaired_sub(pw_batch* b, int32_t k) {
@@ -980,7 +1031,7 @@ static int do_trace(pw_batch* b, const int32_t* d_ends, hipStream_t st) {
   HIP_TRY(pw::launch_trace(p, st));
   for (auto& r : b->repaired) if (replay_trace(b, r.first, r.second, st) != 0) return -1;
   if (b->flags & PW_FLAG_PROFILE) { HIP_TRY(hipEventRecord(b->ev_tr1, st)); b->trace_timed = true; }
-  return 0;
+  return mark_done(b, st);
 }
 
 int pw_batch_traceback(pw_batch* b, void* stream) {
@@ -1057,7 +1108,7 @@ int pw_batch_pack_transcripts(pw_batch* b, void* stream) {
     HIP_TRY(hipMalloc((void**)&b->d_txoffsets, 8 * ((size_t)b->n + 1)));
   }
   HIP_TRY(pw::launch_tx_pack(b->d_pairs, b->d_results, b->d_tx, b->n, b->d_txoffsets, b->d_txpacked, (hipStream_t)stream));
-  return 0;
+  return mark_done(b, (hipStream_t)stream);
 }
 void* pw_batch_packed_device(pw_batch* b) { return b->d_txpacked; }
 void* pw_batch_packed_offsets_device(pw_batch* b) { return b->d_txoffsets; }
@@ -1065,7 +1116,7 @@ int pw_batch_packed_total_async(pw_batch* b, uint64_t* host_out, void* stream) {
   if (!b->d_txoffsets) return fail("pw_batch_packed_total_async before pw_batch_pack_transcripts");
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipMemcpyAsync(host_out, b->d_txoffsets + b->n, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
-  return 0;
+  return mark_done(b, (hipStream_t)stream);
 }
 int pw_batch_packed(pw_batch* b, uint8_t* out, uint64_t cap, uint64_t* offsets_out) {
   if (!b->d_txoffsets) return fail("pw_batch_packed before pw_batch_pack_transcripts");

@@ -74,16 +74,28 @@ int pw_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes);  
 /* Plans the batch (band clamp / feasibility per pair exactly as dptable_init), picks the kernel variants,
  * allocates every device buffer and uploads the descriptors.  The arena is `arena_bytes` long; its
  * contents are supplied later (pw_batch_upload_arena or pw_batch_arena_device).  NULL on error. */
-/* The library keeps the big device buffers of destroyed batches (>= 1 MB each; per device up to PWLIB_POOL_GB, default a
- * quarter of the device's memory, 0 disables) for the next batch on that device; pw_pool_trim releases them all -- call
- * it before handing the GPU's memory to another allocator in the process (torch, RCCL). */
+/* The library keeps the big device buffers of destroyed batches (>= 1 MB each) for the next batch on that device: per
+ * device up to PWLIB_POOL_GB if set (0 disables), otherwise up to a quarter of the device's memory and never more than half
+ * of what is free at the moment a buffer is parked.  pw_pool_trim releases them all -- call it before handing the GPU's
+ * memory to another allocator in the process (torch, RCCL). */
 void pw_pool_trim(void);
 
 pw_batch* pw_batch_create(int device, const pw_scoring* scoring, int32_t n_pairs, const pw_pair* pairs,
                           uint64_t arena_bytes, uint32_t flags);
-/* Waits for the device (every stream) before releasing or parking the batch's buffers, so a batch may be destroyed
- * while its last launches are still in flight. */
+/* Waits for what was launched FOR THIS BATCH (an event per stream it was used on, recorded behind every launch of the
+ * library) before releasing or parking its buffers, so a batch may be destroyed while its last launches are still in
+ * flight, without stalling other batches' streams.  Work the caller itself queued on the batch's buffers (its own kernels
+ * reading pw_batch_results_device, say) is the caller's to wait for. */
 void pw_batch_destroy(pw_batch* b);
+
+/* The planner alone: what pw_batch_create would choose for these problems, computed on the host with no device call and
+ * nothing allocated (works on a machine without a GPU; the tests pin the kernel choices with it).  `kernel` receives the
+ * name pw_batch_kernel_name would report (NUL-terminated, at most kernel_cap bytes); `info`, if not NULL, 8 ints: score
+ * type (0 int32 / 1 double), dyadic scale shift (scores are held times 2^shift), pairs on one-wavefront kernels, on
+ * workgroup kernels, on the tiled kernel, on the strip pipeline, packed rule (-1: not a packed kernel), matrix form (0 / 1).
+ * 0, or -1 with pw_last_error set. */
+int pw_plan_only(const pw_scoring* scoring, int32_t n_pairs, const pw_pair* pairs, uint64_t arena_bytes, uint32_t flags,
+                 char* kernel, int32_t kernel_cap, int32_t* info);
 
 /* per-pair planning results (host side, available right after create) */
 int pw_batch_init_rc(const pw_batch* b, int32_t k);                         /* 0 or -1, as dptable_init */
