@@ -23,5 +23,5 @@ done
 cd $R
 for d in $O/inflight1 $O/default; do f=$(find $d -name '*kernel_stats.csv' | head -1); echo "== $f"; head -6 $f | cut -c1-220; cp $f $O/kernel_stats_$(basename $d).csv; done
 python3 tests/micro/pmc_sum.py $O "k_fill16<8, false, 3, false>" --json $O/pmc_kernel.json --library-name "k_fill16<8, false> x4" --pairs 10000
-tail -1 $O/bench_inflight1.log > $O/bench_inflight1_under_rocprof.json
-tail -1 $O/bench_default.log > $O/bench_default_under_rocprof.json
+grep -h '^{"metric"' $O/bench_inflight1.log > $O/bench_inflight1_under_rocprof.json
+grep -h '^{"metric"' $O/bench_default.log > $O/bench_default_under_rocprof.json
