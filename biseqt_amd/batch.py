@@ -434,3 +434,34 @@ def align_batch(pairs, **kw):
     with BatchAligner(pairs, **kw) as b:
         res = b.run()
         return res, b.transcripts(res)
+
+
+def plan_only(shapes, alnmode=W.STD_MODE, alntype=W.GLOBAL, alphabet_len=4, subst_scores=None, match_score=1, mismatch_score=0,
+              go_score=0, ge_score=0, flags=0):
+    """What :class:`BatchAligner` would choose for problems of these shapes, without a GPU and without allocating anything
+    (``pw_plan_only``): ``shapes`` is a list of ``(origin_len, mutant_len)`` or ``(origin_len, mutant_len, dmin, dmax)``.
+    Returns a dict: ``kernel`` (as :attr:`BatchAligner.kernel_name`), ``score_dtype``, ``scale_shift`` (dyadic scaling:
+    scores held times ``2**shift``), the number of pairs on one-wavefront kernels / workgroup kernels / the tiled kernel /
+    the strip pipeline, ``packed_rule`` (-1 unless a packed 16-bit kernel) and ``matrix`` (packed kernel in matrix form)."""
+    lib = W.load()
+    L = alphabet_len
+    if subst_scores is None:
+        subst_scores = [[match_score if i == j else mismatch_score for i in range(L)] for j in range(L)]
+    S = np.ascontiguousarray(np.asarray(subst_scores, dtype=np.float64).reshape(L, L))
+    sc = W.pw_scoring(alnmode, alntype, L, S.ctypes.data_as(C.POINTER(C.c_double)), float(go_score), float(ge_score))
+    pairs = (W.pw_pair * max(len(shapes), 1))()
+    off = 0
+    for k, sh in enumerate(shapes):
+        X, Y = int(sh[0]), int(sh[1])
+        dmin, dmax = (int(sh[2]), int(sh[3])) if len(sh) > 2 else (0, 0)
+        oo = off
+        off += (X + 15) // 16 * 16 + 16
+        mo = off
+        off += (Y + 15) // 16 * 16 + 16
+        pairs[k] = W.pw_pair(oo, mo, X, Y, dmin, dmax)
+    name = C.create_string_buffer(128)
+    info = (C.c_int32 * 8)()
+    if lib.pw_plan_only(C.byref(sc), len(shapes), pairs, max(off, 16), flags, name, 128, info) != 0:
+        raise RuntimeError('pw_plan_only failed: ' + W.last_error())
+    return dict(kernel=name.value.decode(), score_dtype='f64' if info[0] else 'i32', scale_shift=info[1], one_wavefront=info[2],
+                workgroup=info[3], tiled=info[4], strips=info[5], packed_rule=info[6], matrix=bool(info[7]))
