@@ -435,10 +435,15 @@ int batch_plan(pw_batch* b) {
       if (64 / nl >= 2 && enough && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
     }
     const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
-    if ((latency_mode || nsolv < 1024) && bk1 && !forced) {
-      // fewer pairs than SIMDs: the time is one wavefront's chain of steps, so as few diagonals per lane as the band
-      // allows -- several pairs side by side where they fit, which changes the number of wavefronts, not the chain
-      // (2 kb pairs, band radius 20: 1.41 -> 0.49 ms; radius 50: 0.87 -> 0.49 ms)
+    // pairs that fit one wavefront side by side at the narrowest lanes
+    const int ppw1 = bk1 ? std::max(1, 64 / ((maxnd + bk1 - 1) / bk1)) : 1;
+    if ((latency_mode || nsolv < 1024 * ppw1) && bk1 && !forced) {
+      // fewer wavefronts than SIMDs (side by side): the time is one wavefront's chain of steps, so as few diagonals per
+      // lane as the band allows -- several pairs side by side where they fit, which changes the number of wavefronts, not
+      // the chain (2 kb pairs, band radius 20: 1.41 -> 0.49 ms; radius 50: 0.87 -> 0.49 ms).  Round 3 (found by
+      // tests/micro/planner_check.py): this also holds for 1024 ... 1024 x ppw1 pairs, which used to fall between the two
+      // rules and ran one pair per wavefront, two wavefronts per SIMD -- 2000 pairs of 1 kb with a 21-diagonal band
+      // 0.48 ms, side by side 0.37 ms.
       pbk = bk1; pnl = (maxnd + bk1 - 1) / bk1; pseg = 64 / pnl >= 2 ? 1 : 0;
     }
     else if (want_seg) { pbk = bkp; pnl = nlp; pseg = 1; }

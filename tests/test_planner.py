@@ -56,7 +56,9 @@ def test_few_pairs_one_after_another_or_all_at_once():
 def test_lane_layouts():
     kw = dict(alnmode=1, alntype=1, **CFG)
     # narrow bands: several pairs per wavefront, the fewest diagonals per lane
-    for shapes in ([(100, 100, -10, 10)] * 20000, [(1000, 1000, -10, 10)] * 1000, [(2000, 2000, -20, 20)] * 16):
+    # (2000 pairs: between "fewer pairs than SIMDs" and "enough wavefronts after packing" -- the gap planner_check.py found)
+    for shapes in ([(100, 100, -10, 10)] * 20000, [(1000, 1000, -10, 10)] * 1000, [(2000, 2000, -20, 20)] * 16,
+                   [(1000, 1000, -10, 10)] * 2000):
         assert plan_only(shapes, **kw)['kernel'] == 'k_fill16<4, true> x4', shapes[0]
     # bands wider than one wavefront holds, many pairs: workgroups with narrow lanes (32 diagonals per lane spill)
     r = plan_only([(10000, 10000, -1500, 1500)] * 300, **kw)
