@@ -38,6 +38,10 @@ FILL16_WAVES = {      # (bk, rule, matrix)
     (16, 0, 0): (3, 0), (16, 3, 0): (3, 0),
 }
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
+# The f64 kernels never see a NaN (scores are validated finite, sums stay far from overflow): telling the compiler so lets
+# v_max_f64 take values that crossed lanes as bit patterns without a canonicalising v_max_f64 x, x in front.  It licenses no
+# reassociation and no contraction (-ffp-contract=off stays): every add is still the reference's add.
+F64_FLAGS = {'f64': ['-fno-honor-nans']}
 # objects whose kernels get a fingerprint in biseqt_amd/pwlib/kernel_hashes.json (config 2's and config 3's fill kernels)
 HASHED_OBJECTS = ('pw_fill16_bk8_r3.o', 'pw_fill16_bk8_r0.o', 'pw_fill_i32_bk8.o', 'pw_fill_f64_bk8.o', 'pw_strip.o')
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
@@ -48,16 +52,16 @@ def _jobs():
     for tn, t in TYPES:
         for bk in BKS:
             obj = os.path.join(OBJ_DIR, 'pw_fill_%s_bk%d.o' % (tn, bk))
-            cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
+            cmd = [HIPCC] + COMMON + F64_FLAGS.get(tn, []) + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
                                       os.path.join(HERE, 'pw_fill_tu.hip'), '-o', obj]
             jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tu.hip')]))
     for tn, t in TYPES:
         obj = os.path.join(OBJ_DIR, 'pw_fill_mw_%s.o' % tn)
-        cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_mw_tu.hip'), '-o', obj]
+        cmd = [HIPCC] + COMMON + F64_FLAGS.get(tn, []) + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_mw_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_mw_tu.hip')]))
     for tn, t in TYPES:
         obj = os.path.join(OBJ_DIR, 'pw_fill_tile_%s.o' % tn)
-        cmd = [HIPCC] + COMMON + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_tile_tu.hip'), '-o', obj]
+        cmd = [HIPCC] + COMMON + F64_FLAGS.get(tn, []) + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-c', os.path.join(HERE, 'pw_fill_tile_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tile_tu.hip')]))
     for bk, rule, mat in [(bk, r, 0) for r in PACKED_RULES for bk in PACKED_BKS] + [(bk, r, 1) for r in PACKED_MAT_RULES for bk in PACKED_BKS]:
         obj = os.path.join(OBJ_DIR, 'pw_fill16_bk%d_r%d%s.o' % (bk, rule, '_mat' if mat else ''))

@@ -18,8 +18,31 @@
 
 namespace pw {
 
+// m + m + flag as ONE v_addc_co_u32 whose carry-in is the flag's lane mask (the compiler would select a 0 / 1 and shift-or)
+PW_FN uint32_t dev_shl1_in(uint32_t m, bool flag) {
+  const uint64_t mask = __builtin_amdgcn_ballot_w64(flag);
+  uint32_t r;
+  uint64_t cout;
+  asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(r), "=s"(cout) : "v"(m), "s"(mask));
+  return r;
+}
+
+// A substitution score out of the table (pw_wave.h, TAB): `off` is a byte offset.  ALWAYS_LDS: the table is known to sit in
+// LDS at compile time -- a ds_read by 32-bit address, no flat load, no 64-bit address arithmetic; otherwise asked at run time
+// (wave-uniform) and read from LDS or from global memory.
+template <typename T, bool ALWAYS_LDS> PW_FN T dev_tab_read(const T* tab, uint32_t handle, uint32_t off, bool in_lds) {
+  typedef __attribute__((address_space(3))) const T lds_T;
+  if (ALWAYS_LDS || in_lds) return *(lds_T*)(uintptr_t)(handle + off);
+  return *(const T*)((const char*)tab + off);
+}
+PW_FN uint32_t dev_lds_handle(const void* p) {      // the LDS address of a __shared__ object
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 // Platform policy of the lane program on a CDNA wave64.
 struct DevP {
+  template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
+  PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   PW_FN static int lane() { return (int)(threadIdx.x & 63u); }
   // DPP wave shifts: lane i receives lane i-1 (shr) / i+1 (shl); the lane with no source keeps `old`.
   PW_FN static int32_t shr1(int32_t v, int32_t old) {
@@ -28,6 +51,9 @@ struct DevP {
   PW_FN static int32_t shl1(int32_t v, int32_t old) {
     return __builtin_amdgcn_update_dpp(old, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
   }
+  // the same shifts with zero fill (bound_ctrl): no dependence on an old value, so no copy in front of the DPP move
+  PW_FN static int32_t shr1z(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true); }
+  PW_FN static int32_t shl1z(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true); }
   PW_FN static int32_t shfl_xor(int32_t v, int m) { return __shfl_xor(v, m, 64); }
   PW_FN static int32_t uniform(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
   PW_FN static int nlanes() { return 64; }
@@ -85,6 +111,8 @@ template <int N, int MAXW> PW_FN void wg_shift_left(int32_t* v, const int32_t* o
 // boundary goes through LDS (one slot per wavefront, written by its edge lane) between two workgroup barriers.
 // Every wavefront runs the same sequence of shifts, so the barriers are reached uniformly.
 struct DevPM {
+  template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
+  PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   PW_FN static int lane() { return (int)threadIdx.x; }
   PW_FN static int lane0() { return 0; }
   PW_FN static bool central() { return true; }
@@ -133,9 +161,10 @@ constexpr int kMaxLdsL = 32;   // substitution tables up to 32 x 32 are staged i
 #endif
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
 __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a) {
-  __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
+  constexpr bool TAB = true;      // (pw_wave.h: the substitution score is read from a table)
+  __shared__ T sub_lds[TAB ? kMaxLdsL * kMaxLdsL : 1];
   const T* tab = a.subst;
-  if (GENERIC) {
+  if (TAB) {
     if (a.L <= kMaxLdsL) {
       for (int i = (int)threadIdx.x; i < a.L * a.L; i += 64) sub_lds[i] = a.subst[i];
       __syncthreads();
@@ -146,6 +175,7 @@ __global__ __launch_bounds__(64) PW_FILL_ATTR void k_fill(const FillParams<T> a)
   const int pair = a.order ? a.order[slot] : slot;
   const PairDesc pd = a.pairs[pair];
   WaveFill<DevP, T, BK, BANY, TRACK, GENERIC> w(a, pd, tab);
+  w.tab_handle = dev_lds_handle(sub_lds); w.tab_in_lds = tab == sub_lds;
   w.pair_slot = pair;
   w.run();
 }
@@ -190,6 +220,8 @@ __global__ __launch_bounds__(512) void k_fill16_mw(const FillParams<int32_t> a) 
 // kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.
 constexpr int kTileLanes = PW_TILE_LANES, kTileGhost = PW_TILE_GHOST, kTileCentral = kTileLanes - 2 * kTileGhost;
 struct DevPT {
+  template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
+  PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   // Workgroups are dealt to the 8 XCDs round-robin; neighbouring tiles exchange their state through memory between
   // launches, so tile t = (b mod 8) * (grid / 8) + b / 8 keeps runs of consecutive tiles on one XCD (and its L2).
   // (The grid is a multiple of 8; tiles beyond the band find no diagonal and do nothing.)
@@ -252,9 +284,10 @@ static_assert(kTileBK == kTileBKHost && kTileCentral == kTileCentralLanes && kTi
 // K2b: one launch = one time block (tile_nb <= kTileGhost * kTileBK / 16 blocks) of ONE pair; grid = tiles.
 template <typename T, bool BANY, bool TRACK, bool GENERIC>
 __global__ __launch_bounds__(kTileLanes) void k_fill_tile(const FillParams<T> a, const int pair) {
-  __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
+  constexpr bool TAB = true;      // (pw_wave.h: the substitution score is read from a table)
+  __shared__ T sub_lds[TAB ? kMaxLdsL * kMaxLdsL : 1];
   const T* tab = a.subst;
-  if (GENERIC) {
+  if (TAB) {
     if (a.L <= kMaxLdsL) {
       for (int i = (int)threadIdx.x; i < a.L * a.L; i += (int)blockDim.x) sub_lds[i] = a.subst[i];
       __syncthreads();
@@ -263,6 +296,7 @@ __global__ __launch_bounds__(kTileLanes) void k_fill_tile(const FillParams<T> a,
   }
   const PairDesc pd = a.pairs[pair];
   WaveFill<DevPT, T, kTileBK, BANY, TRACK, GENERIC> w(a, pd, tab);
+  w.tab_handle = dev_lds_handle(sub_lds); w.tab_in_lds = tab == sub_lds;
   w.pair_slot = pair;
   w.run_tile();
 }
@@ -337,9 +371,10 @@ hipError_t launch_tile_finish_T(const FillParams<T>& a, int pair, hipStream_t st
 // pair over 8 wavefronts beats one wavefront working through 16 or 32 diagonals per lane.
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
 __global__ __launch_bounds__(512) void k_fill_mw(const FillParams<T> a) {
-  __shared__ T sub_lds[GENERIC ? kMaxLdsL * kMaxLdsL : 1];
+  constexpr bool TAB = true;      // (pw_wave.h: the substitution score is read from a table)
+  __shared__ T sub_lds[TAB ? kMaxLdsL * kMaxLdsL : 1];
   const T* tab = a.subst;
-  if (GENERIC) {
+  if (TAB) {
     if (a.L <= kMaxLdsL) {
       for (int i = (int)threadIdx.x; i < a.L * a.L; i += (int)blockDim.x) sub_lds[i] = a.subst[i];
       __syncthreads();
@@ -350,6 +385,7 @@ __global__ __launch_bounds__(512) void k_fill_mw(const FillParams<T> a) {
   const int pair = a.order ? a.order[slot] : slot;
   const PairDesc pd = a.pairs[pair];
   WaveFill<DevPM, T, BK, BANY, TRACK, GENERIC> w(a, pd, tab);
+  w.tab_handle = dev_lds_handle(sub_lds); w.tab_in_lds = tab == sub_lds;
   w.pair_slot = pair;
   w.run();
 }

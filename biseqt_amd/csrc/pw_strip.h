@@ -177,10 +177,11 @@ struct StripFill {
     const int32_t Un = Hn + (bD ? vge : vgego), Ln = Hn + (bI ? vge : vgego);
     // the M bit stays 0: with go <= 0 the walker never looks at it (the first kept op is M exactly when none of
     // B, D, I is kept: pw_first_op)
-    const uint32_t nib = (bB ? (uint32_t)MB : 0u) | (bD ? (uint32_t)MD : 0u) | (bI ? (uint32_t)MI : 0u);
+    // (the nibble is shifted into the mask word flag by flag: a plain shift for the M bit, then one add-with-carry per flag
+    //  -- P::shl1_in, m + m + flag with the comparison's lane mask as carry-in -- instead of three selects, two ORs and a shift)
     Hdiag = Hin;
     if (RAMP) {
-      macc = (macc << 4) | (active ? nib : 0u);
+      macc = P::shl1_in(P::shl1_in(P::shl1_in(macc << 1, bI && active), bD && active), bB && active);
       Hout = active ? Hn : Hout; Uout = active ? Un : Uout; Lo = active ? Ln : Lo;
       if (active && y == a.Y) hlast = Hn;
       if (TRACK) {
@@ -188,7 +189,7 @@ struct StripFill {
         best = upd ? Hn : best; bestY = upd ? y : bestY;
       }
     } else if (MODE == 3) {
-      macc = (macc << 4) | nib;
+      macc = P::shl1_in(P::shl1_in(P::shl1_in(macc << 1, bI), bD), bB);
       Hout = Hn; Uout = Un; Lo = Ln;
       // the row's last cell is computed on step kY = Y + lane; cells after it are virtual.  The running key takes them too,
       // so its value at that step is set aside (block<3> then picks, per lane, the snapshot, the key or nothing)
@@ -202,7 +203,7 @@ struct StripFill {
     } else {
       // (MODE 1: the masks of virtual cells are never visited by the walker, and their scores lose against any real
       //  cell's in the row's running best)
-      macc = (macc << 4) | nib;
+      macc = P::shl1_in(P::shl1_in(P::shl1_in(macc << 1, bI), bD), bB);
       Hout = Hn; Uout = Un; Lo = Ln;
       if (TRACK && (MODE == 0 || MODE == 4)) {
         // every cell is a real one here (|H| < 2^25): one shift-or and one max instead of compare, two selects and the

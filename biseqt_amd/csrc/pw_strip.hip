@@ -14,6 +14,7 @@
 namespace pw {
 
 struct DevPS {
+  PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   PW_FN static int lane() { return (int)(threadIdx.x & 63u); }
   PW_FN static int32_t shr1(int32_t v, int32_t old) {
     return __builtin_amdgcn_update_dpp(old, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);

@@ -44,11 +44,26 @@ template <> struct ScoreTraits<int32_t> {
   // two sentinels still fits an int32.
   PW_FN static int32_t neg() { return -(1 << 28); }
   PW_FN static int32_t zero_blk() { return 0; }
+  // (the forms the floating-point path uses; for integers they are the plain expressions)
+  PW_FN static int32_t max2(int32_t a, int32_t b) { return a > b ? a : b; }
+  PW_FN static int32_t gap_offer(bool kept, int32_t go, int32_t A) { return kept ? A : A + go; }
 };
 template <> struct ScoreTraits<double> {
   static constexpr bool is_int = false;
   PW_FN static double neg() { return -1.0e300; }
   PW_FN static double zero_blk() { return -0.0; }   // x + (-0.0) == x bit for bit, also for x = +-0
+  // The larger of two (finite) scores as ONE instruction (v_max_f64) instead of compare + two selects.  Same value as the
+  // reference's "replace when strictly greater" (pw.c:92-103); only the sign of a zero may differ (documented exception).
+  PW_FN static double max2(double a, double b) { return __builtin_fmax(a, b); }
+  // A gap offer out of a cell whose own score + ge is `A`: A + go unless the same gap op is kept in the cell
+  // (_pw_internals.c:268-278), as ONE fused multiply-add on a 0.0 / 1.0 factor whose high dword is the only thing selected:
+  // fma(1, go, A) = round(go + A), the reference's (H + ge) + go; fma(0, go, A) = A.  Exact, no double rounding: the
+  // product is 0 or go itself.  (Compare + add + two 32-bit selects otherwise.)
+  union D2I_ { double d; int32_t i[2]; };
+  PW_FN static double gap_offer(bool kept, double go, double A) {
+    D2I_ f; f.i[0] = 0; f.i[1] = kept ? 0 : 0x3ff00000;
+    return __builtin_fma(f.d, go, A);
+  }
 };
 
 // ---- cross-lane moves for any score type, built on the platform's 32-bit wave shifts -----------
@@ -90,6 +105,16 @@ template <class P, bool LEFT> PW_FN void xshift_pair(int32_t& s, int32_t sold, u
 }
 template <class P, bool LEFT> PW_FN void xshift_pair(double& s, double sold, uint32_t& w, uint32_t wold, int phase) {
   D2I a, b; a.d = s; b.d = sold;
+  if constexpr (!P::kBatchedShifts) {
+    // Every caller passes "no such predecessor" as the edge lane's value, and such a value only has to be hugely negative:
+    // its HIGH dword decides that.  So the low dword moves with a zero-filling shift (no copy of a constant in front of the
+    // DPP move), the high dword with the constant.
+    a.i[0] = LEFT ? P::shl1z(a.i[0]) : P::shr1z(a.i[0]);
+    a.i[1] = LEFT ? P::shl1(a.i[1], b.i[1]) : P::shr1(a.i[1], b.i[1]);
+    w = (uint32_t)(LEFT ? P::shl1((int32_t)w, (int32_t)wold) : P::shr1((int32_t)w, (int32_t)wold));
+    s = a.d;
+    return;
+  }
   int32_t v[3] = {a.i[0], a.i[1], (int32_t)w}; const int32_t o[3] = {b.i[0], b.i[1], (int32_t)wold};
   if (LEFT) xshlv<P, 3>(v, o, phase); else xshrv<P, 3>(v, o, phase);
   a.i[0] = v[0]; a.i[1] = v[1]; s = a.d; w = (uint32_t)v[2];
@@ -133,6 +158,13 @@ struct WaveFill {
   static constexpr int R = BK / 2;
   static constexpr bool TRACK = TRACK_ || GENERIC;
   using Tr = ScoreTraits<T>;
+  // TAB: the substitution score is READ from a table (LDS on the device) instead of selected by a letter comparison: one
+  // add for the address and a read that does not occupy the vector ALU, against compare + select (+ a second select for a
+  // 64-bit value).  It also makes ANY substitution matrix -- BLOSUM-style integer matrices over 20 letters, full log-odds
+  // matrices -- exactly as cheap as match / mismatch scoring on these kernels (round 2 sent every matrix to the generic
+  // kernel).  The letter windows hold byte offsets: the origin letter times the row size, the mutant letter times the
+  // element size.  (Round 3; `false` restores the comparison for integer scores.)
+  static constexpr bool TAB = true;
 
   // ---- uniform (per pair) ----
   const FillParams<T>& a;
@@ -154,16 +186,25 @@ struct WaveFill {
   PW_FN WaveFill(const FillParams<T>& a_, const PairDesc& pd_, const T* sub_tab_)
       : a(a_), pd(pd_), sub_tab(sub_tab_) {}
 
+  // (the table sits in LDS -- always for the fast f64 kernels, whose planner admits alphabets of up to kMaxLdsL letters
+  //  only; the generic kernels also take larger alphabets, from global memory, and ask at run time)
+  uint32_t tab_handle = 0;      // the platform's handle of the LDS copy (P::tab_read)
+  bool tab_in_lds = false;
   PW_FN T subst(uint32_t oc, uint32_t mc) const {
-    if (GENERIC) return sub_tab[oc * (uint32_t)a.L + mc];
+    if (TAB) {      // (pre-scaled letters: see TAB)
+      if (!GENERIC) return P::template tab_read<T, true>(sub_tab, tab_handle, oc + mc, true);
+      return P::template tab_read<T, false>(sub_tab, tab_handle, oc + mc, tab_in_lds);
+    }
     return oc == mc ? a.match : a.mismatch;
   }
+  PW_FN uint32_t osc() const { return TAB ? (uint32_t)a.L * (uint32_t)sizeof(T) : 1u; }
+  PW_FN uint32_t msc() const { return TAB ? (uint32_t)sizeof(T) : 1u; }
 
   // One cell of slot J on step t (lane-local coordinates x, y).
   template <bool RAMP, int J>
-  PW_FN void cell(T up, T left, uint32_t oc, uint32_t mc, int x, int y, int t) {
+  PW_FN void cell(T up, T left, T sub, int x, int y, int t) {
     const T hD = up, hI = left;
-    const T hM = H[J] + subst(oc, mc);
+    const T hM = H[J] + sub;
     bool active = true;
     bool ball;
     if (RAMP) {
@@ -184,10 +225,9 @@ struct WaveFill {
       const T b0 = ball ? T(0) : Tr::neg();
       Hn = b0 > Hn ? b0 : Hn;
     } else {
-      Hn = ball ? T(0) : hD;
-      if (ball) Hn = hD > Hn ? hD : Hn;
-      Hn = hI > Hn ? hI : Hn;
-      Hn = hM > Hn ? hM : Hn;
+      // (an alignment that may not begin here: "no such predecessor" as the begin candidate, as the integer path does)
+      const T b0 = ball ? T(0) : Tr::neg();
+      Hn = Tr::max2(Tr::max2(Tr::max2(b0, hD), hI), hM);
     }
     const bool bB = ball && (Hn == T(0));
     const bool bD = (hD == Hn), bI = (hI == Hn), bM = (hM == Hn);
@@ -202,9 +242,8 @@ struct WaveFill {
         Un = Hn + (bD ? a.ge : gego);
         Ln = Hn + (bI ? a.ge : gego) + blkL[J];
       } else {
-        const T Bv = A + a.go;
-        Un = bD ? A : Bv;
-        Ln = (bI ? A : Bv) + blkL[J];
+        Un = Tr::gap_offer(bD, a.go, A);
+        Ln = Tr::gap_offer(bI, a.go, A) + blkL[J];
       }
     } else {
       const T Bv = A + a.go;
@@ -213,10 +252,11 @@ struct WaveFill {
       Un = bD ? (oD ? hi : A) : Bv;
       Ln = (bI ? (oI ? hi : A) : Bv) + blkL[J];
     }
-    const uint32_t nib = (bB ? (uint32_t)MB : 0u) | (bD ? (uint32_t)MD : 0u) |
-                         (bI ? (uint32_t)MI : 0u) | (bM ? (uint32_t)MM : 0u);
+    // the tie nibble (M, I, D, B from bit 3 down: MM, MI, MD, MB) is shifted into the slot's mask word one flag at a time:
+    // on the device each P::shl1_in is ONE add-with-carry whose carry-in is the comparison's lane mask (m + m + flag), four
+    // instructions per cell instead of four selects, the ORs and the shift
     if (RAMP) {
-      m[J] = (m[J] << 4) | (active ? nib : 0u);
+      m[J] = P::shl1_in(P::shl1_in(P::shl1_in(P::shl1_in(m[J], bM && active), bI && active), bD && active), bB && active);
       H[J] = active ? Hn : H[J];
       U[J] = active ? Un : U[J];
       L[J] = active ? Ln : L[J];
@@ -226,11 +266,12 @@ struct WaveFill {
         bestT[J] = upd ? t : bestT[J];
       }
     } else {
-      m[J] = (m[J] << 4) | nib;
+      m[J] = P::shl1_in(P::shl1_in(P::shl1_in(P::shl1_in(m[J], bM), bI), bD), bB);
       H[J] = Hn; U[J] = Un; L[J] = Ln;
       if (TRACK) {
         const bool upd = Hn > best[J];
-        best[J] = upd ? Hn : best[J];
+        if (Tr::is_int) best[J] = upd ? Hn : best[J];
+        else best[J] = Tr::max2(best[J], Hn);           // (one v_max_f64 instead of two selects)
         bestT[J] = upd ? t : bestT[J];
       }
     }
@@ -243,22 +284,33 @@ struct WaveFill {
   }
 
   // compile-time loops over the slots of one parity
+  // (AHEAD: the substitution scores of the step were read from the table a step earlier -- sE / sO, see iteration())
   template <bool RAMP, int I> struct EvenLoop {
     PW_FN static void run(WaveFill& w, T uin, int t) {
-      w.template cell<RAMP, 2 * I>(I == 0 ? uin : w.U[(2 * I - 1 + BK) % BK], w.L[2 * I + 1], w.ow[I], w.mw[I],
-                                   w.xbase + I, w.ybase - I, t);
+      w.template cell<RAMP, 2 * I>(I == 0 ? uin : w.U[(2 * I - 1 + BK) % BK], w.L[2 * I + 1],
+                                   AHEAD ? w.sE[I] : w.subst(w.ow[I], w.mw[I]), w.xbase + I, w.ybase - I, t);
       EvenLoop<RAMP, I + 1>::run(w, uin, t);
     }
   };
   template <bool RAMP> struct EvenLoop<RAMP, R> { PW_FN static void run(WaveFill&, T, int) {} };
   template <bool RAMP, int I> struct OddLoop {
     PW_FN static void run(WaveFill& w, T lin, int t) {
-      w.template cell<RAMP, 2 * I + 1>(w.U[2 * I], I == R - 1 ? lin : w.L[(2 * I + 2) % BK], w.ow[I], w.mw[I],
-                                       w.xbase + I + 1, w.ybase - I, t);
+      w.template cell<RAMP, 2 * I + 1>(w.U[2 * I], I == R - 1 ? lin : w.L[(2 * I + 2) % BK],
+                                       AHEAD ? w.sO[I] : w.subst(w.ow[I], w.mw[I]), w.xbase + I + 1, w.ybase - I, t);
       OddLoop<RAMP, I + 1>::run(w, lin, t);
     }
   };
   template <bool RAMP> struct OddLoop<RAMP, R> { PW_FN static void run(WaveFill&, T, int) {} };
+
+  // AHEAD (single-wavefront platforms): the letters do not depend on the arithmetic, so their two window moves run ahead of
+  // it and every table read is issued a whole STEP before the cell that needs it -- the odd step's at the start of the even
+  // step, the next even step's at the start of the odd step -- instead of a few instructions before (a table read takes
+  // ~100 cycles; with two wavefronts per SIMD nothing else covers it).  Platforms whose shifts cross wavefronts through LDS
+  // move a letter and a score in ONE exchange and keep the letters in step with the arithmetic.
+  static constexpr bool AHEAD = TAB && !P::kBatchedShifts;
+  T sE[AHEAD ? R : 1], sO[AHEAD ? R : 1];
+  PW_FN static T shift_score_l(T v) { T r = v; uint32_t none = 0; xshift_pair<P, true>(r, Tr::neg(), none, 0u, 0); return r; }
+  PW_FN static T shift_score_r(T v) { T r = v; uint32_t none = 0; xshift_pair<P, false>(r, Tr::neg(), none, 0u, 0); return r; }
 
   // One iteration = the even step 2*it and the odd step 2*it + 1.
   template <bool RAMP>
@@ -267,13 +319,39 @@ struct WaveFill {
     // previous iteration, together with the mutant window)
     T uin = uin_next;
     if (P::kVirtualLanes) uin = lane == 0 ? Tr::neg() : uin;    // nothing lies below diagonal 0 of the band
+    if constexpr (AHEAD) {
+      // origin window as of the odd step (lane l takes lane l+1's lowest letter, the last lane is fed from the arena)
+      {
+        const uint32_t oin = (uint32_t)P::shl1((int32_t)ow[0], (int32_t)(feed_byte(fo_lo, fo_hi, k) * osc()));
+#pragma unroll
+        for (int i = 0; i + 1 < R; i++) ow[i] = ow[i + 1];
+        ow[R - 1] = oin;
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++) sO[i] = subst(ow[i], mw[i]);           // the odd step's scores: a step ahead
+      EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
+      const T lin = shift_score_l(L[0]);
+      // mutant window as of the next iteration (lane l takes lane l-1's highest letter, lane 0 is fed from the arena)
+      {
+        const uint32_t min_ = (uint32_t)P::shr1((int32_t)mw[R - 1], (int32_t)(feed_byte(fm_lo, fm_hi, k) * msc()));
+#pragma unroll
+        for (int i = R - 1; i > 0; i--) mw[i] = mw[i - 1];
+        mw[0] = min_;
+      }
+#pragma unroll
+      for (int i = 0; i < R; i++) sE[i] = subst(ow[i], mw[i]);           // the next even step's scores
+      OddLoop<RAMP, 0>::run(*this, lin, 2 * it + 1);
+      uin_next = shift_score_r(U[BK - 1]);
+      xbase++; ybase++;
+      return;
+    }
     EvenLoop<RAMP, 0>::run(*this, uin, 2 * it);
     // one exchange to the left: the origin window moves on by one letter (lane l takes lane l+1's lowest
     // letter, the last lane is fed from the arena) and the last slot gets its "left" offer for the odd step
     T lin = L[0];
     {
       uint32_t oin = ow[0];
-      xshift_pair<P, true>(lin, Tr::neg(), oin, feed_byte(fo_lo, fo_hi, k), it & 1);
+      xshift_pair<P, true>(lin, Tr::neg(), oin, feed_byte(fo_lo, fo_hi, k) * osc(), it & 1);
 #pragma unroll
       for (int i = 0; i + 1 < R; i++) ow[i] = ow[i + 1];
       ow[R - 1] = oin;
@@ -284,7 +362,7 @@ struct WaveFill {
     {
       uint32_t min_ = mw[R - 1];
       uin_next = U[BK - 1];
-      xshift_pair<P, false>(uin_next, Tr::neg(), min_, feed_byte(fm_lo, fm_hi, k), it & 1);
+      xshift_pair<P, false>(uin_next, Tr::neg(), min_, feed_byte(fm_lo, fm_hi, k) * msc(), it & 1);
 #pragma unroll
       for (int i = R - 1; i > 0; i--) mw[i] = mw[i - 1];
       mw[0] = min_;
@@ -369,8 +447,12 @@ struct WaveFill {
     }
 #pragma unroll
     for (int i = 0; i < R; i++) {
-      ow[i] = oseq[pw_clampi(xbase + i - 1, 0, olast)];
-      mw[i] = mseq[pw_clampi(ybase - i - 1, 0, mlast)];
+      ow[i] = (uint32_t)oseq[pw_clampi(xbase + i - 1, 0, olast)] * osc();
+      mw[i] = (uint32_t)mseq[pw_clampi(ybase - i - 1, 0, mlast)] * msc();
+    }
+    if (AHEAD) {
+#pragma unroll
+      for (int i = 0; i < (AHEAD ? R : 1); i++) sE[i] = subst(ow[i], mw[i]);
     }
   }
 

@@ -345,9 +345,10 @@ int batch_plan(pw_batch* b) {
   b->use_f64 = (b->flags & PW_FLAG_FORCE_F64) || !integral || (double)maxspan * maxabs >= (double)(1 << 27);
   const bool bany = b->brule == pw::BRULE_ANY;
   const bool track = b->endrule == pw::END_STD_LOCAL || b->endrule == pw::END_BANDED_LOCAL;
-  // (a matrix the packed kernels take: planned like match / mismatch scoring first; whatever does not end up on a packed
-  //  kernel falls back to the generic one below)
-  if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || (!b->simple && !mat_ok) || b->go > 0) b->variant = pw::VAR_GENERIC;
+  // A substitution matrix needs no kernel of its own: the wavefront kernels read every substitution score from a table in
+  // LDS (pw_wave.h, TAB), the packed kernels take small integer matrices as rows of bytes (mat_ok).  The generic kernel is
+  // left with what is decided at run time: go > 0, the score-plane dump, and alphabets beyond the LDS copy (32 letters).
+  if ((b->flags & (PW_FLAG_FORCE_GENERIC | PW_FLAG_DUMP_SCORES)) || b->go > 0 || L > 32) b->variant = pw::VAR_GENERIC;
   else if (bany) b->variant = pw::VAR_FAST_ANY_TRACK;
   else if (track) b->variant = pw::VAR_FAST_TRACK;
   else b->variant = pw::VAR_FAST;
@@ -377,7 +378,7 @@ int batch_plan(pw_batch* b) {
   else if (b->variant == pw::VAR_FAST_ANY_TRACK && b->endrule == pw::END_CORNER) prule = 4;
   // (START_ANCHORED: begin at (0, 0) like GLOBAL, end at the first best cell, which must beat 0)
   else if (b->variant == pw::VAR_FAST_TRACK && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_STD_LOCAL) prule = 5;
-  if (!b->simple && prule > 2) prule = -1;          // (the matrix form is built for rules 0 .. 3)
+  if (!b->simple && (prule > 2 || !mat_ok)) prule = -1;   // (the packed matrix form: rules 0 .. 3, matrices it admits)
   if (prule >= 4 && env_int("PWLIB_NO_PACKED_ANCHORED", 0)) prule = -1;
   bool pfits = false;
   // (any substitution may be the best one: the API accepts mismatch > match)
@@ -463,10 +464,7 @@ int batch_plan(pw_batch* b) {
     }
     if (pbk) b->variant = pw::VAR_FAST16;
   }
-  if (!b->simple) {
-    if (b->variant == pw::VAR_FAST16) b->packed_mat = 1;
-    else b->variant = pw::VAR_GENERIC;              // a matrix off the packed kernels: substitution table in LDS
-  }
+  if (!b->simple && b->variant == pw::VAR_FAST16) b->packed_mat = 1;
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {
     pw::PairDesc& d = b->descs[k];
@@ -475,7 +473,7 @@ int batch_plan(pw_batch* b) {
     bool tiled = false;
     // (scores within +-2^25: the strip kernel tracks a row's best as 32 * H + step)
     const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && (double)maxspan * maxabs < (double)(1 << 25) &&
-                          b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 &&
+                          b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 && b->simple &&
                           !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED | PW_FLAG_NO_STRIP)) && !env_int("PWLIB_NO_STRIP", 0);
     // ... always for tables wider than a workgroup holds; and for batches of a few pairs (at most 256: latency mode) when the
     // strips of all pairs, one pair after another, are estimated to finish before the slowest workgroup would (2 kb x 2 kb:

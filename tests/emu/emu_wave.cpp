@@ -74,9 +74,13 @@ struct Emu {
 Emu* Emu::self = nullptr;
 
 struct EmuP {
+  template <typename T, bool A> static T tab_read(const T* tab, uint32_t, uint32_t off, bool) { return *(const T*)((const char*)tab + off); }
+  static uint32_t shl1_in(uint32_t m, bool flag) { return (m << 1) | (flag ? 1u : 0u); }
   static int lane() { return Emu::self->cur; }
   static int32_t shr1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur - 1, old); }
   static int32_t shl1(int32_t v, int32_t old) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, old); }
+  static int32_t shr1z(int32_t v) { Emu* e = Emu::self; return e->exchange(v, e->cur - 1, 0); }
+  static int32_t shl1z(int32_t v) { Emu* e = Emu::self; return e->exchange(v, e->cur + 1, 0); }
   static int32_t shfl_xor(int32_t v, int m) { Emu* e = Emu::self; return e->exchange(v, e->cur ^ m, 0); }
   static int32_t uniform(int32_t v) { return v; }
   static int nlanes() { return 64; }

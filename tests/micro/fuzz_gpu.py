@@ -23,7 +23,28 @@ SCORES = [(1, -3, -5, -2), (1, 0, 0, 0), (2, -1, 0, -1), (5, -4, -10, -1), (1, -
           (1, -1, 2, -3), (100, -100, -100, -100), (0, 0, 0, 0), (1, -3, 0, -2), (2, -3, -5, 0),
           (1, 6, -5, -2), (2, 3, -1, -1),      # mismatch > match: the API accepts it
           (-1, -2, -3, -1), (-1, 2, -2, -1), (-2, 0, -1, 0),   # ... and a negative match score
-          (0.5, -0.25, -1.5, -0.75), (1.3862943611198906, -0.8754687373538999, -2.995732273553991, -0.6931471805599453)]
+          (0.5, -0.25, -1.5, -0.75), (1.3862943611198906, -0.8754687373538999, -2.995732273553991, -0.6931471805599453),
+          # round 3: dyadic score sets (scaled exactly onto the integer kernels), config 5's extension scores first
+          (0.25, -1, 0, -1), (0.5, -1.5, -2.5, -1), (1.25, -0.75, -0.5, -0.25), (2, -3.125, -4.5, -0.0625), (0.75, 1.5, -0.25, -0.5)]
+
+
+def make_matrix(rng, L):
+    """Round 3: a substitution matrix instead of match / mismatch -- small integers (the packed kernels' byte rows when L <= 4),
+    larger integers and larger alphabets (the wavefront kernels' table in LDS), dyadic and arbitrary floats."""
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        S = rng.integers(-6, 7, size=(L, L)).astype(np.float64)
+    elif kind == 1:
+        S = rng.integers(-40, 41, size=(L, L)).astype(np.float64)
+    elif kind == 2:
+        S = rng.integers(-3, 4, size=(L, L)).astype(np.float64); S = (S + S.T) / 2            # halves: dyadic
+    elif kind == 3:
+        S = rng.integers(-200, 300, size=(L, L)).astype(np.float64)
+    else:
+        S = np.round(rng.normal(0, 2, size=(L, L)), 3)
+    if rng.random() < 0.7:
+        S[np.arange(L), np.arange(L)] = np.abs(S[np.arange(L), np.arange(L)]) + 1
+    return [[float(v) for v in row] for row in S]
 FLAGS = [0, 0, 0, W.PW_FLAG_NO_PACKED16, W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_GENERIC, W.PW_FLAG_FORCE_TILED,
          W.PW_FLAG_FORCE_TILED | W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_STRIP, W.PW_FLAG_FORCE_STRIP]
 
@@ -96,13 +117,20 @@ def run(budget, seed, long_mode=False, max_batches=None):
             o, m = make_pair(rng, L, maxlen)
             pairs.append((o, m))
             bands.append(make_band(rng, len(o), len(m), o, m))
-        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, match_score=sc[0], mismatch_score=sc[1],
-                  go_score=sc[2], ge_score=sc[3], flags=flags, check_band=False)
+        subst = make_matrix(rng, L) if (not long_mode and rng.random() < 0.3) else None
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, go_score=sc[2], ge_score=sc[3], flags=flags, check_band=False)
+        if subst is not None:
+            kw['subst_scores'] = subst
+            if flags & W.PW_FLAG_FORCE_STRIP:
+                kw['flags'] = flags = 0                        # (the strips serve match / mismatch scoring only)
+        else:
+            kw.update(match_score=sc[0], mismatch_score=sc[1])
         if mode == 1:
             kw['diag_range'] = bands
         # kernel selection knobs the planner reads at batch creation: throughput kernels for small batches, the unscaled
         # packed kernel where the scaled one would be taken
-        for name, p_on in (('PWLIB_LATENCY_MODE', 0.3), ('PWLIB_NO_SCALED16', 0.3)):
+        for name, p_on in (('PWLIB_LATENCY_MODE', 0.3), ('PWLIB_NO_SCALED16', 0.3), ('PWLIB_NO_DYADIC', 0.15), ('PWLIB_NO_PACKED_MAT', 0.15),
+                           ('PWLIB_NO_PACKED_ANCHORED', 0.15)):
             os.environ.pop(name, None)
             if rng.random() < p_on:
                 os.environ[name] = '0' if name == 'PWLIB_LATENCY_MODE' else '1'
@@ -118,7 +146,11 @@ def run(budget, seed, long_mode=False, max_batches=None):
             continue
         nb += 1
         for k, (o, m) in enumerate(pairs):
-            okw = dict(L=L, mode=mode, alntype=alntype, match=sc[0], mismatch=sc[1], go=sc[2], ge=sc[3])
+            okw = dict(L=L, mode=mode, alntype=alntype, go=sc[2], ge=sc[3])
+            if subst is not None:
+                okw['subst'] = subst
+            else:
+                okw.update(match=sc[0], mismatch=sc[1])
             if mode == 1:
                 okw['diag_range'] = bands[k]
             r = O.solve(o, m, **okw)
@@ -139,15 +171,15 @@ def run(budget, seed, long_mode=False, max_batches=None):
                         why = 'expected NULL traceback, got %r' % txs[k][:20]
             if why:
                 nbad += 1
-                print('MISMATCH %s | kernel %s mode %d type %d scores %s flags %d L %d band %s X %d Y %d'
-                      % (why, kname, mode, alntype, sc, flags, L, bands[k] if mode else None, len(o), len(m)))
+                print('MISMATCH %s | kernel %s mode %d type %d scores %s flags %d L %d band %s X %d Y %d matrix %s'
+                      % (why, kname, mode, alntype, sc, flags, L, bands[k] if mode else None, len(o), len(m), subst))
                 if nbad <= 3 and os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
                     np.savez(os.path.join(ROOT, 'gpurun_out', 'fuzz_bad_%d.npz' % nbad), o=o, m=m, band=np.array(bands[k]),
                              meta=np.array([mode, alntype, flags, L]), sc=np.array(sc, dtype=np.float64))
         if time.time() - last > 30:
             last = time.time()
             print('... %d batches, %d pairs, %d bad' % (nb, npairs, nbad), flush=True)
-    for name in ('PWLIB_LATENCY_MODE', 'PWLIB_NO_SCALED16'):      # (the knobs must not outlive the run: pytest calls it in-process)
+    for name in ('PWLIB_LATENCY_MODE', 'PWLIB_NO_SCALED16', 'PWLIB_NO_DYADIC', 'PWLIB_NO_PACKED_MAT', 'PWLIB_NO_PACKED_ANCHORED'):      # (the knobs must not outlive the run: pytest calls it in-process)
         os.environ.pop(name, None)
     print('kernels: ' + ', '.join('%s x%d' % kv for kv in sorted(kernels.items(), key=lambda kv: -kv[1])))
     print('fuzz: %d batches, %d pairs, %d mismatches (seed %d, %.0f s)' % (nb, npairs, nbad, seed, time.time() - t0))

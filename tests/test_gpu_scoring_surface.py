@@ -271,3 +271,57 @@ def test_anchored_types_on_their_packed_kernels(oracle, alntype, tag):
         assert (res == res32).all() and txs == txs32, (name, kw)
         okw = dict(L=4, mode=0, alntype=alntype, match=match, mismatch=mismatch, go=go, ge=ge)
         _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, max(1, n // 40), (name, kw))
+
+
+def test_float_matrices_on_the_fast_f64_kernels(oracle):
+    """A full matrix of float scores (what a log-odds model with unequal substitution probabilities gives) used to take the
+    generic f64 kernel; the fast f64 kernels now read every substitution score from the table in LDS, so it runs on them:
+    named (not the generic instantiation `<double, BK, false, true, true>`), equal to the forced generic kernel for every pair
+    and to the oracle on samples -- alphabets of 4 and 20 letters; 40 letters (table too large for the LDS copy) stay generic."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3700)
+    for L, fast in ((4, True), (20, True), (40, False)):
+        P = rng.uniform(0.02, 1.0, size=(L, L)) + np.eye(L) * 4
+        P = P / P.sum(axis=1, keepdims=True)
+        subst = [[float(np.log(0.9) + np.log(P[i][j]) - np.log(1.0 / L)) for j in range(L)] for i in range(L)]
+        go, ge = float(np.log(0.05) - np.log(0.1)), float(np.log(0.1))
+        for mode, alntype, dr in ((1, 1, (-30, 30)), (0, 0, None), (1, 2, (-40, 40))):
+            pairs = _pairs(rng, 300, 10, 220, L=L)
+            kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, subst_scores=subst, go_score=go, ge_score=ge)
+            if dr is not None:
+                kw['diag_range'] = dr
+            name, dtype, res, txs, rcs = _run(pairs, **kw)
+            nameg, _, resg, txsg, _ = _run(pairs, flags=W.PW_FLAG_FORCE_GENERIC, **kw)
+            assert dtype == 'f64' and 'double' in name, name
+            assert name.endswith('false, true, true>') != fast or 'k_fill_mw' in name or 'k_fill_tile' in name, (name, L)
+            assert (res == resg).all() and txs == txsg, (name, L, mode)
+            okw = dict(L=L, mode=mode, alntype=alntype, diag_range=dr, subst=subst, go=go, ge=ge)
+            _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, 17, (name, L))
+
+
+def test_protein_style_integer_matrix_on_the_fast_kernels(oracle):
+    """An integer matrix over 20 letters (BLOSUM-style: the packed kernels' byte rows hold 4 letters only) runs on the fast
+    32-bit kernels, which read every substitution score from a table in LDS, not on the generic kernel: equal to the forced
+    generic kernel for every pair and to the oracle on samples; also through the workgroup (wide band) and tiled kernels."""
+    from biseqt_amd import _pwlib as W
+    from biseqt_amd import synth
+    rng = synth.rng_for(3800)
+    L = 20
+    S = rng.integers(-4, 4, size=(L, L))
+    S = (S + S.T) // 2
+    S[np.arange(L), np.arange(L)] = rng.integers(4, 12, size=L)
+    subst = [[int(v) for v in row] for row in S]
+    for mode, alntype, dr, n, lo, hi, flags in ((1, 1, (-30, 30), 300, 10, 300, 0), (0, 0, None, 300, 10, 200, 0), (1, 2, (-40, 40), 300, 50, 400, 0),
+                                                (0, 1, None, 3, 1200, 1500, 0), (0, 1, None, 2, 500, 700, W.PW_FLAG_FORCE_TILED)):
+        pairs = _pairs(rng, n, lo, hi, L=L)
+        kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, subst_scores=subst, go_score=-10, ge_score=-1)
+        if dr is not None:
+            kw['diag_range'] = dr
+        name, dtype, res, txs, rcs = _run(pairs, flags=flags, **kw)
+        assert dtype == 'i32' and not name.endswith('false, true, true>'), name
+        if not flags:
+            nameg, _, resg, txsg, _ = _run(pairs, flags=W.PW_FLAG_FORCE_GENERIC, **kw)
+            assert (res == resg).all() and txs == txsg, (name, nameg)
+        okw = dict(L=L, mode=mode, alntype=alntype, diag_range=dr, subst=[[float(v) for v in row] for row in subst], go=-10, ge=-1)
+        _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, max(1, n // 20), name)

@@ -80,10 +80,18 @@ def test_scoring_surface_admissions():
     shapes = [(2000, 2010, -200, 200)] * 1000
     r = plan_only(shapes, subst_scores=BLASTISH, go_score=-5, ge_score=-2, **base)
     assert r['kernel'] == 'k_fill16<8, false> x4 matrix' and r['matrix']
-    # five letters, go > 0: the generic kernel; scores too large for 16 bits: the 32-bit kernel; not dyadic: f64
-    r5 = plan_only(shapes, alphabet_len=5, subst_scores=[[1 if i == j else -1 - (i + j) % 3 for j in range(5)] for i in range(5)],
-                   go_score=-5, ge_score=-2, **base)
-    assert r5['kernel'] == 'k_fill<int, 8, false, true, true>'
+    # a matrix the packed kernels do not admit (five letters; BLOSUM-like, 20 letters): the fast 32-bit kernel -- every
+    # wavefront kernel reads its substitution scores from a table in LDS -- not the generic one; 40 letters (beyond the LDS
+    # copy) and go > 0: the generic kernel; scores too large for 16 bits: the 32-bit kernel; not dyadic: f64
+    for L in (5, 20):
+        rL = plan_only(shapes, alphabet_len=L, subst_scores=[[4 if i == j else -1 - (i + j) % 3 for j in range(L)] for i in range(L)],
+                       go_score=-5, ge_score=-2, **base)
+        assert rL['kernel'] == 'k_fill<int, 8, true, true, false>', (L, rL)
+    r40 = plan_only(shapes, alphabet_len=40, subst_scores=[[4 if i == j else -1 - (i + j) % 3 for j in range(40)] for i in range(40)],
+                    go_score=-5, ge_score=-2, **base)
+    assert r40['kernel'] == 'k_fill<int, 8, false, true, true>'
+    logodds = [[0.8 if i == j else -1.7 + 0.01 * (i + j) for j in range(4)] for i in range(4)]
+    assert plan_only(shapes, subst_scores=logodds, go_score=-0.69, ge_score=-1.2, **base)['kernel'] == 'k_fill<double, 8, true, true, false>'
     assert plan_only(shapes, match_score=1, mismatch_score=-3, go_score=2, ge_score=-2, **base)['kernel'] == 'k_fill<int, 8, false, true, true>'
     assert plan_only(shapes, match_score=100, mismatch_score=-300, go_score=-500, ge_score=-200, **base)['kernel'] == 'k_fill<int, 8, true, true, false>'
     assert plan_only(shapes, match_score=0.1, mismatch_score=-1, go_score=0, ge_score=-1, **base)['score_dtype'] == 'f64'
