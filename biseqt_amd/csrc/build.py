@@ -41,7 +41,12 @@ TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 # The f64 kernels never see a NaN (scores are validated finite, sums stay far from overflow): telling the compiler so lets
 # v_max_f64 take values that crossed lanes as bit patterns without a canonicalising v_max_f64 x, x in front.  It licenses no
 # reassociation and no contraction (-ffp-contract=off stays): every add is still the reference's add.
-F64_FLAGS = {'f64': ['-fno-honor-nans']}
+F64_FLAGS = {'f64': ['-fno-honor-nans'] + os.environ.get('PW_F64_EXTRA_CXXFLAGS', '').split()}     # (the extra flags: A/B builds)
+# Scheduling strategy per (score type, diagonals per lane) of the wavefront kernels, where an A/B on the GPU decided: the f64
+# kernel with 8 diagonals per lane (config 2's shape: 7.75 -> 7.50 ms with max-ilp; 255 VGPRs instead of 243, still two
+# wavefronts per SIMD).  The narrower f64 bodies would drop a wavefront per SIMD (BK = 4: 127 -> 154 VGPRs), the 32-bit
+# BK = 8 body too (159 -> 172): they keep the default.
+FILL_EXTRA = {('f64', 8): ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 # objects whose kernels get a fingerprint in biseqt_amd/pwlib/kernel_hashes.json (config 2's and config 3's fill kernels)
 HASHED_OBJECTS = ('pw_fill16_bk8_r3.o', 'pw_fill16_bk8_r0.o', 'pw_fill_i32_bk8.o', 'pw_fill_f64_bk8.o', 'pw_strip.o')
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
@@ -52,7 +57,7 @@ def _jobs():
     for tn, t in TYPES:
         for bk in BKS:
             obj = os.path.join(OBJ_DIR, 'pw_fill_%s_bk%d.o' % (tn, bk))
-            cmd = [HIPCC] + COMMON + F64_FLAGS.get(tn, []) + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
+            cmd = [HIPCC] + COMMON + F64_FLAGS.get(tn, []) + FILL_EXTRA.get((tn, bk), []) + ['-DPW_T=' + t, '-DPW_TNAME=' + tn, '-DPW_BK=%d' % bk, '-c',
                                       os.path.join(HERE, 'pw_fill_tu.hip'), '-o', obj]
             jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill_tu.hip')]))
     for tn, t in TYPES:
@@ -158,7 +163,8 @@ def build(force=False, verbose=True):
         if verbose:
             print('[build] linked', SO)
     shutil.copyfile(os.path.join(ROOT, 'include', 'pwlib.h'), os.path.join(OUT_DIR, 'pwlib.h'))
-    hashes = os.path.join(OUT_DIR, 'kernel_hashes.json')
+    # (an A/B build under another PW_SO_NAME keeps its fingerprints beside its own library)
+    hashes = os.path.join(OUT_DIR, 'kernel_hashes.json' if os.path.basename(SO) == 'pwlib.so' else os.path.basename(SO) + '.hashes.json')
     if force or todo or not os.path.exists(hashes):
         # Fingerprints of the kernels whose rocprofv3 counters are quoted from committed files (profiles/pmc_kernel.json):
         # bench.py reports those counters only while the kernel it runs still has the code they were collected on.
