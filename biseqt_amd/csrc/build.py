@@ -36,7 +36,14 @@ PACKED_MAT_RULES = (0, 1, 2, 3)        # ... with a substitution matrix of up to
 FILL16_WAVES = {      # (bk, rule, matrix)
     (8, 0, 0): (5, 0), (8, 3, 0): (5, 0),
     (16, 0, 0): (3, 0), (16, 3, 0): (3, 0),
+    # the matrix form (round 3): 206 VGPRs left alone, 165 at 3 per SIMD without a spill (4 spills): config 2's shape with a
+    # 4 x 4 matrix 3.65-3.71 ms against 3.78-3.80 (A/B of two builds on one box) -- level with the match / mismatch form
+    (8, 0, 1): (3, 0), (8, 3, 1): (3, 0),
 }
+# A/B builds: PW_FILL16_WAVES_OVERRIDE="8,3,1=3,0;8,0,1=3,0" replaces / adds entries (bk,rule,matrix=one-pair,lane-packed)
+for _e in filter(None, os.environ.get('PW_FILL16_WAVES_OVERRIDE', '').split(';')):
+    _k, _v = _e.split('=')
+    FILL16_WAVES[tuple(int(x) for x in _k.split(','))] = tuple(int(x) for x in _v.split(','))
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 # The f64 kernels never see a NaN (scores are validated finite, sums stay far from overflow): telling the compiler so lets
 # v_max_f64 take values that crossed lanes as bit patterns without a canonicalising v_max_f64 x, x in front.  It licenses no

@@ -782,6 +782,7 @@ struct WaveFill16 {
   uint32_t OW[RH], MW[RH];
   uint32_t ROW[MAT ? R : 1];                            // MAT: the matrix row of every cell's origin letter
   uint32_t BIASV, MADJ;                                 // MAT: -min(subst) in both halves; the selector fix-up of the mutant window
+  uint32_t MR0, MR1, MR2, MR3;                          // MAT: the four rows of the matrix
   uint32_t ONE, SH15, C2, C4, C16, NDELTA, MATCHV, GOV, GOVI, NEGV, LIMV;
   // RULE 0, steady blocks: the running best of a slot as a key 8 H + (7 - cell within the block) -- one multiply-add and
   // one unsigned maximum per cell pair instead of maximum, compare, subtract and multiply-add (H <= 8191: the planner
@@ -1040,8 +1041,14 @@ struct WaveFill16 {
     return (d < 0 ? -d : d) - pd.s0;                       // the first cell of the diagonal lies on the table edge
   }
   // MAT: the row of origin letter l (uniform rows, selected by compares: scalar code where l is wave-uniform)
+  // (the rows are copied out of the kernel arguments once -- MR0 .. MR3 -- so that the selection is a chain of selects on
+  //  values already in registers; read in place, each arm became a load behind a branch, and a branch in the unrolled block
+  //  serialises the packed ops)
   PW_FN uint32_t row_of(uint32_t l) const {
-    return l == 0u ? a.mat_rows[0] : (l == 1u ? a.mat_rows[1] : (l == 2u ? a.mat_rows[2] : (l == 3u ? a.mat_rows[3] : 0u)));
+    uint32_t r = l == 3u ? MR3 : 0u;
+    r = l == 2u ? MR2 : r;
+    r = l == 1u ? MR1 : r;
+    return l == 0u ? MR0 : r;
   }
   PW_FN uint32_t row_at(int i) const { return (uint32_t)i < (uint32_t)X ? row_of((uint32_t)oseq[i]) : 0u; }
   PW_FN uint32_t msel_lo(int i) const { return (uint32_t)i < (uint32_t)Y ? (MSEL | (uint32_t)mseq[i]) : MSENT_LO; }
@@ -1077,6 +1084,7 @@ struct WaveFill16 {
     // the multipliers of the "not kept" values: 0 / 1 each, or (SC4) 0 / 2 for D and 0 / 4 for I
     GOV = pk::both(SC4 ? 2 * a.go : a.go); GOVI = pk::both(a.go);
     BIASV = pk::both(a.mat_bias); MADJ = 0x0003fffcu;
+    MR0 = a.mat_rows[0]; MR1 = a.mat_rows[1]; MR2 = a.mat_rows[2]; MR3 = a.mat_rows[3];
     if (MAT) {
 #pragma unroll
       for (int i = 0; i < (MAT ? R : 1); i++) ROW[i] = row_at(xbase + i - 1);
