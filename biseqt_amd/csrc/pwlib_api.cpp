@@ -465,6 +465,11 @@ int batch_plan(pw_batch* b) {
     if (pbk) b->variant = pw::VAR_FAST16;
   }
   if (!b->simple && b->variant == pw::VAR_FAST16) b->packed_mat = 1;
+  // Match / mismatch scoring over at most 4 letters IS such a matrix, and the matrix form's cell pair is an op shorter
+  // (one v_perm_b32 instead of xor, min and multiply-add): A/B knob, see DESIGN.md K1
+  if (b->simple && b->variant == pw::VAR_FAST16 && prule >= 0 && prule <= 2 && L >= 2 && L <= 4 && integral && smin <= 0 &&
+      smax - smin <= 127 && env_int("PWLIB_SIMPLE_AS_MATRIX", 0) && !env_int("PWLIB_NO_PACKED_MAT", 0))
+    b->packed_mat = 1;
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {
     pw::PairDesc& d = b->descs[k];
