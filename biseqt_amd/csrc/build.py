@@ -55,7 +55,7 @@ F64_FLAGS = {'f64': ['-fno-honor-nans'] + os.environ.get('PW_F64_EXTRA_CXXFLAGS'
 # BK = 8 body too (159 -> 172): they keep the default.
 FILL_EXTRA = {('f64', 8): ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 # objects whose kernels get a fingerprint in biseqt_amd/pwlib/kernel_hashes.json (config 2's and config 3's fill kernels)
-HASHED_OBJECTS = ('pw_fill16_bk8_r3.o', 'pw_fill16_bk8_r0.o', 'pw_fill_i32_bk8.o', 'pw_fill_f64_bk8.o', 'pw_strip.o')
+HASHED_OBJECTS = ('pw_fill16_bk8_r3_mat.o', 'pw_fill16_bk8_r3.o', 'pw_fill16_bk8_r0.o', 'pw_fill_i32_bk8.o', 'pw_fill_f64_bk8.o', 'pw_strip.o')
 HEADERS = ['pw_types.h', 'pw_wave.h', 'pw_strip.h', 'pw_plan.h', 'pw_launch.h', 'pw_device.h']
 
 

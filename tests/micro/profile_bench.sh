@@ -22,6 +22,6 @@ for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 done
 cd $R
 for d in $O/inflight1 $O/default; do f=$(find $d -name '*kernel_stats.csv' | head -1); echo "== $f"; head -6 $f | cut -c1-220; cp $f $O/kernel_stats_$(basename $d).csv; done
-python3 tests/micro/pmc_sum.py $O "k_fill16<8, false, 3, false>" --json $O/pmc_kernel.json --library-name "k_fill16<8, false> x4" --pairs 10000
+python3 tests/micro/pmc_sum.py $O "k_fill16<8, false, 3, true>" --json $O/pmc_kernel.json --library-name "k_fill16<8, false> x4 matrix" --pairs 10000
 grep -h '^{"metric"' $O/bench_inflight1.log > $O/bench_inflight1_under_rocprof.json
 grep -h '^{"metric"' $O/bench_default.log > $O/bench_default_under_rocprof.json

@@ -281,7 +281,8 @@ def test_config2_properties_full_size(oracle):
     with BatchAligner(list(zip(origins, mutants)), alnmode=1, alntype=1, alphabet_len=4,
                       diag_range=(-200, 200), match_score=1, mismatch_score=-3, go_score=-5, ge_score=-2) as b:
         assert b.score_dtype == 'i32'
-        assert b.kernel_name == 'k_fill16<8, false> x4'   # the kernel bench.py's headline line reports (scores held times 4)
+        # the kernel bench.py's headline line reports (scores held times 4; match / mismatch fed through the matrix form)
+        assert b.kernel_name == 'k_fill16<8, false> x4 matrix'
         cells = b.cells
         res = b.run()
         txs = b.transcripts(res)
@@ -324,18 +325,23 @@ def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
     kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-200, 200), match_score=1, mismatch_score=-3,
               go_score=-5, ge_score=-2)
     runs = {}
-    for name, flags in (('packed16', 0), ('packed16_unscaled', 0), ('int32', W.PW_FLAG_NO_PACKED16), ('f64', W.PW_FLAG_FORCE_F64)):
-        if name == 'packed16_unscaled':
-            os.environ['PWLIB_NO_SCALED16'] = '1'
+    for name, flags, env in (('packed16', 0, {}), ('packed16_plain', 0, {'PWLIB_SIMPLE_AS_MATRIX': '0'}),
+                             ('packed16_unscaled', 0, {'PWLIB_NO_SCALED16': '1'}),
+                             ('packed16_plain_unscaled', 0, {'PWLIB_NO_SCALED16': '1', 'PWLIB_SIMPLE_AS_MATRIX': '0'}),
+                             ('int32', W.PW_FLAG_NO_PACKED16, {}), ('f64', W.PW_FLAG_FORCE_F64, {})):
+        os.environ.update(env)
         try:
             with BatchAligner(pairs, flags=flags, **kw) as b:
                 kname = b.kernel_name
                 res = b.run()
                 runs[name] = (kname, res.copy(), b.transcripts(res))
         finally:
-            os.environ.pop('PWLIB_NO_SCALED16', None)
-    assert runs['packed16'][0] == 'k_fill16<8, false> x4'
-    assert runs['packed16_unscaled'][0] == 'k_fill16<8, false>'
+            for key in env:
+                os.environ.pop(key, None)
+    assert runs['packed16'][0] == 'k_fill16<8, false> x4 matrix'
+    assert runs['packed16_plain'][0] == 'k_fill16<8, false> x4'
+    assert runs['packed16_unscaled'][0] == 'k_fill16<8, false> matrix'
+    assert runs['packed16_plain_unscaled'][0] == 'k_fill16<8, false>'
     assert runs['int32'][0] == 'k_fill<int, 8, true, true, false>'
     assert runs['f64'][0] == 'k_fill<double, 8, true, true, false>'
     kname, res, txs = runs['packed16']
@@ -352,7 +358,7 @@ def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
                          match=1, mismatch=-3, go=-5, ge=-2)
         assert (res['opt_i'][k], res['opt_j'][k]) == r['opt'] and res['score'][k] == r['score'], k
         assert txs[k] == r['transcript'], k
-    for other in ('packed16_unscaled', 'int32', 'f64'):
+    for other in ('packed16_plain', 'packed16_unscaled', 'packed16_plain_unscaled', 'int32', 'f64'):
         _, res2, txs2 = runs[other]
         assert (res2 == res).all(), other
         assert txs2 == txs, other

@@ -2,6 +2,7 @@
 kernel choices DESIGN.md describes are pinned here shape by shape, so that a change of the timing model
 (biseqt_amd/csrc/pw_model.h) or of an admission rule shows up as a failing line, not as a silent slowdown.  Whether each
 choice is still the FASTEST one is the GPU's to say: tests/test_gpu_planner.py."""
+import os
 import pytest
 
 from biseqt_amd import _pwlib as W
@@ -20,7 +21,18 @@ def test_baseline_configs():
     assert r['kernel'].startswith('k_fill_mw<int, 4') and r['workgroup'] == 1
     # config 2: the packed kernel, scores held times 4, one pair per wavefront, 8 diagonals per lane
     r = plan_only([(2000, 2010, -200, 200)] * 10000, alnmode=1, alntype=1, **CFG)
-    assert r['kernel'] == 'k_fill16<8, false> x4' and r['one_wavefront'] == 10000 and r['score_dtype'] == 'i32'
+    assert r['kernel'] == 'k_fill16<8, false> x4 matrix' and r['one_wavefront'] == 10000 and r['score_dtype'] == 'i32'
+    # (match / mismatch over 4 letters runs on the matrix form where that measured faster; the knob restores the plain form)
+    os.environ['PWLIB_SIMPLE_AS_MATRIX'] = '0'
+    try:
+        r = plan_only([(2000, 2010, -200, 200)] * 10000, alnmode=1, alntype=1, **CFG)
+    finally:
+        os.environ.pop('PWLIB_SIMPLE_AS_MATRIX')
+    assert r['kernel'] == 'k_fill16<8, false> x4' and not r['matrix']
+    # ... not lane-packed, not under the overlap rule, not at 16 diagonals per lane (level there)
+    assert plan_only([(2000, 2010, -200, 200)] * 10000, alnmode=1, alntype=2, **CFG)['kernel'] == 'k_fill16<8, false, 1>'
+    assert plan_only([(2000, 2010, -400, 400)] * 3000, alnmode=1, alntype=1, **CFG)['kernel'] == 'k_fill16<16, false> x4'
+    assert plan_only([(1000, 1000)] * 5000, alnmode=0, alntype=0, **CFG)['kernel'] == 'k_fill16<32, false, 2> matrix'
     # config 3: the strip pipeline
     r = plan_only([(100000, 100218)], alnmode=0, alntype=1, **CFG)
     assert r['kernel'] == 'k_fill_strip<true> x row strips'
