@@ -109,12 +109,12 @@ _AGPR_OK = (re.compile(r'^v_accvgpr_write_b32 a[0-3], 0\b'),
 
 
 def strip_kernel_violations(obj_path):
-    """Empty list when k_fill_strip<true|false> keep the invariants the asm relies on; otherwise what broke."""
+    """Empty list when the four k_fill_strip<TRACK, BROW> keep the invariants the asm relies on; otherwise what broke."""
     bad = []
     md = kernel_metadata(obj_path)
     strip = {n: k for n, k in md.items() if 'k_fill_strip' in n}
-    if len(strip) != 2:
-        bad.append('expected 2 k_fill_strip instantiations, found %d' % len(strip))
+    if len(strip) != 4:
+        bad.append('expected 4 k_fill_strip instantiations, found %d' % len(strip))
     for n, k in strip.items():
         if k.get('agpr_count') != 4:
             bad.append('%s: agpr_count %s != 4 (the compiler allocated accumulation registers of its own)' % (n, k.get('agpr_count')))

@@ -80,7 +80,11 @@ PW_FN uint64_t strip_mask_index(int nkq, int w, int q, int lane) {      // in dw
   return ((uint64_t)((uint64_t)w * nkq + q) * 64 + lane) * 4;
 }
 
-template <class P, bool TRACK>
+// BROW (byte rows): alphabets of at most 4 letters and scores that fit a signed byte -- the lane holds its row of the
+// substitution table as 4 bytes (rowreg: byte m = score of the row's letter against mutant letter m), ONE v_perm_b32 turns
+// the 4 mutant letters of a group of 4 steps into their 4 scores, and a step adds its byte, sign-extended, to the diagonal
+// predecessor in one SDWA add -- instead of a byte compare, a select and an add per step.
+template <class P, bool TRACK, bool BROW = false>
 struct StripFill {
   static constexpr int32_t NEG = -(1 << 28);       // "no such predecessor" (pw_wave.h, ScoreTraits<int32_t>)
 #ifndef PW_STRIP_ROLL_START
@@ -104,6 +108,7 @@ struct StripFill {
   int32_t ksnap, kY;          // MODE 3: the key as it was on the step of the row's last cell; that step (Y + lane)
   int32_t bqv;                // MODE 4: the begin candidate of this lane's current cell (moves down one lane per step)
   uint32_t oc;
+  uint32_t rowreg;            // BROW: the scores of the row's letter against mutant letters 0 .. 3, one byte each
   // the mutant letters this lane meets: lane i needs m[k - 1 - i] at step k, so over the 4 steps of a group (k = 4 g ..
   // 4 g + 3) the 4 bytes that begin at byte 3 - (i mod 4) of the dword pair m32[g - 1 - i / 4], m32[g - i / 4] -- the
   // byte offset is fixed per lane, and the dword a lane needs next is the one the lane 4 below it needed a group ago
@@ -125,6 +130,10 @@ struct StripFill {
   const uint64_t* fin;        // the FIFO row of the strip above or null
   bool cross_out;             // the strip below runs on another XCD: write the row through to memory
   bool cross_in;              // the strip above ran on another XCD: read its row from memory, not from this XCD's L2
+  // per-lane constants of the fast hand-over (FAST blocks): lanes 16 .. 31 expect the tag (epoch, column), every other lane
+  // the "nothing loaded" tag 0 -- so ONE comparison over all 64 lanes says whether the sub-chunk has arrived
+  uint32_t wtag, wm255;       // lanes 16 .. 31: epoch << 8 and 255; else 0 and 0
+  int32_t we0;                // lane - 16: this lane's column within a sub-chunk that sits in lanes 16 .. 31
 
   PW_FN explicit StripFill(const StripParams& a_) : a(a_) {}
   PW_FN void stamp(int i) { if (a.stamps != nullptr && lane == 0) a.stamps[(uint64_t)w * 8 + i] = P::clock(); }
@@ -138,7 +147,7 @@ struct StripFill {
   //         the capture of its last cell look at the column.  (The slowest ~100-step stretch of a strip's life sets
   //         the pace of the whole pipeline: each strip trails the one above by that many columns.)
   template <int MODE>
-  PW_FN void step(int k, int j /* step within the block */, uint32_t& macc, uint32_t mc /* this lane's mutant letter */) {
+  PW_FN void step(int k, int j /* step within the block */, uint32_t& macc, uint32_t x4 /* the group's 4 letters | scores */, int s4) {
     constexpr bool RAMP = MODE == 2;
     // lane 0 takes the feeders' lane-0 values; the feeders then move down a lane (what enters at lane 63 is never used:
     // zero fill, so the shifted copy does not depend on the old one and the old register can take the shift below)
@@ -148,7 +157,7 @@ struct StripFill {
     const int32_t Uin = P::shr1(Uout, fU);
     const int y = k - lane;
     const int32_t hD = Uin, hI = Lo;
-    const int32_t hM = Hdiag + (oc == mc ? vmatch : vmis);
+    const int32_t hM = Hdiag + (BROW ? P::sbyte_of(x4, s4) : (oc == P::byte_of(x4, s4) ? vmatch : vmis));
     bool active = true;
     int32_t bq = b0;
     if (RAMP) {
@@ -246,21 +255,59 @@ struct StripFill {
   template <int SLOT>
   PW_FN void load_sub(int S, int first) const {
     const int e = SUB * S + lane - first;
+    P::template slot_zero<SLOT>();
     if (lane >= first && lane < first + SUB && e <= a.Y) P::template fifo_load_async<SLOT>(fin + e, cross_in);
   }
+#ifndef PW_STRIP_FAST
+#define PW_STRIP_FAST 1     /* 0: every block hands over through the general code (A/B) */
+#endif
+  // FAST blocks (steady ones and the first two of a strip below the first; run() admits them only when every column the
+  // hand-overs of the block touch exists): the same hand-over without the range checks.
+  //   load   columns c0 .. c0 + 15 into lanes 16 .. 31 of SLOT
+  template <int SLOT>
+  PW_FN void load_fast(int c0) const {
+    P::template slot_zero<SLOT>();
+    if ((unsigned)we0 < (unsigned)SUB) P::template fifo_load_async<SLOT>(fin + (c0 + we0), cross_in);
+  }
+  //   merge  the sub-chunk whose first column is c0 (sub-chunk S1) from SLOT into the feeders; VM = vector memory operations
+  //          issued after its load.  Tags are compared in all lanes at once (wtag / wm255); anything but "all there" goes
+  //          through the general code, which polls.  Lanes 16 .. 31 of the feeders are written by a DPP move with a row mask.
+  template <int SLOT, int VM>
+  PW_FN void merge_fast(int c0, int S1) {
+    const uint64_t t = P::template wait_vm<SLOT, VM>();
+    const uint32_t want = ((uint32_t)(c0 + we0) & wm255) | wtag;
+    if (!P::all((uint32_t)(t >> 32) == want)) { merge_value(t, S1, SUB); return; }
+    const int32_t pk = (int32_t)(uint32_t)t;
+    const int32_t h = pk >> 1;
+    const int32_t u = h + ((pk & 1) ? vge : vgego);
+    cH = P::row1(cH, h); cU = P::row1(cU, u);
+  }
+  //   flush  lane 63's cells of steps k0 .. k0 + 15 (lanes 48 .. 63 of gP): columns k0 - 63 .. k0 - 48, all <= Y here
+  PW_FN void flush_fast(int k0) {
+    if (fout == nullptr) return;
+    const int y = k0 + lane - (64 - SUB) - 63;
+    if (lane >= 64 - SUB && y >= 0) {
+      const uint64_t g = ((uint64_t)tag_of(y) << 32) | (uint64_t)(uint32_t)gP;
+      if (cross_out) P::fifo_store(fout + y, g);
+      else P::fifo_store_local(fout + y, g);
+    }
+  }
   // Checks that the granules of sub-chunk S (in `t`, lanes first ..) carry their tags -- polling for those that do not --
-  // and puts them into the feeders of those lanes.  False if the wait was abandoned.
-  PW_FN bool merge_value(uint64_t t, int S, int first, int count = SUB) {
+  // and puts them into the feeders of those lanes.  A wait that is abandoned raises the abort flag and ENDS THE WAVEFRONT
+  // on the spot (P::exit_wave: every other wavefront leaves at its next look at the flag, the host sees the flag): nothing
+  // above this function carries a "gave up" result, which keeps the hand-over code of the steady loop free of it.
+  PW_FN void give_up() {
+    P::flag_set(a.ctl + kStripAbort);
+    P::exit_wave();
+  }
+  PW_FN void merge_value(uint64_t t, int S, int first, int count = SUB) {
     const int e = SUB * S + lane - first;
     const bool mine = lane >= first && lane < first + count;
     const bool need = mine && e <= a.Y;
     const uint32_t want = tag_of(e);
     int spins = 0;
     while (!P::all(!need || (uint32_t)(t >> 32) == want)) {
-      if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
-        P::flag_set(a.ctl + kStripAbort);
-        return false;
-      }
+      if (++spins > a.spin_limit || ((spins & 63) == 0 && P::uniform((int32_t)P::flag_poll(a.ctl + kStripAbort)) != 0)) give_up();
       P::sleep();
       if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + e) : P::fifo_poll_local(fin + e);
     }
@@ -268,7 +315,6 @@ struct StripFill {
     const int32_t h = need ? (pk >> 1) : NEG;
     const int32_t u = need ? h + ((pk & 1) ? a.ge : a.ge + a.go) : NEG;
     cH = mine ? h : cH; cU = mine ? u : cU;
-    return true;
   }
   PW_FN void store_masks() {
     if (mprev_q < 0) return;
@@ -305,37 +351,51 @@ struct StripFill {
   // steps to complete.  (On gfx9-family targets loads and stores share one counter, so a wait for "everything" drains the
   // stores: ~1.2 us, once per hand-over, was the cost of not counting.)
   template <int MODE, int J>
-  PW_FN bool sub_block(int q, uint32_t (&mw)[4]) {
+  PW_FN void sub_block(int q, uint32_t (&mw)[4]) {
     const int S = NSB * q + J;
     const int k0 = kStripBlock * q + SUB * J;
     constexpr int SLOT = (J & 1) ? 0 : 1;                // sub-chunk S + 1: odd for even J
+    constexpr bool FAST = (MODE == 0 || MODE == 4) && !PW_STRIP_MID && PW_STRIP_FAST;
     if (fin == nullptr) {
       // no row above: "no predecessor" keeps entering the feeders where the granules would (the shift fills with zeros)
-      const bool mine = lane >= SUB && lane < 2 * SUB;
-      cH = mine ? NEG : cH; cU = mine ? NEG : cU;
+      if (FAST) { cH = P::row1(cH, NEG); cU = P::row1(cU, NEG); }
+      else {
+        const bool mine = lane >= SUB && lane < 2 * SUB;
+        cH = mine ? NEG : cH; cU = mine ? NEG : cU;
+      }
     }
 #if !PW_STRIP_MID
+    else if (FAST) {
+      // (steady blocks: q >= 2, so the mask store of block q - 1 always sits behind the load that J = 1 waits for)
+      if ((J & 1) && (MODE == 0 || q > 0)) merge_fast<SLOT, 1>(k0 + SUB, S + 1);
+      else merge_fast<SLOT, 0>(k0 + SUB, S + 1);
+    }
     else {
       // J odd: the mask store of block q - 1 was issued behind the load (there is none in front of block 0)
       const uint64_t t = ((J & 1) && q > 0) ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>();
-      if (!merge_value(t, S + 1, SUB)) return false;
+      merge_value(t, S + 1, SUB);
     }
 #endif
-    const bool flushed = flush_out(k0 - SUB);
+    bool flushed = false;
+    if (FAST) { if (MODE == 0) flush_fast(k0 - SUB); }   // (MODE 4: steps 0 .. 47 hold no cell of lane 63)
+    else flushed = flush_out(k0 - SUB);
     (void)flushed;
 #pragma unroll
     for (int h = 0; h < SUB / 8; h++) {                  // one mask dword per 8 steps
       const int hb = J * (SUB / 8) + h;                  // 8-step group within the block
       if (h == SUB / 16) {
 #if !PW_STRIP_MID
-        if (fin != nullptr) load_sub<1 - SLOT>(S + 2, SUB);
+        if (fin != nullptr) {
+          if (FAST) load_fast<1 - SLOT>(SUB * (S + 2));
+          else load_sub<1 - SLOT>(S + 2, SUB);
+        }
 #else
         if (fin != nullptr) {
           if (S >= 1) {                                  // (run() put sub-chunks 0 and 1 into the feeders)
             const int younger = (((J & 1) && q > 0) ? 1 : 0) + (flushed ? 1 : 0);
             const uint64_t t = younger == 2 ? P::template wait_vm<SLOT, 2>()
                                             : (younger == 1 ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>());
-            if (!merge_value(t, S + 1, SUB / 2)) return false;
+            merge_value(t, S + 1, SUB / 2);
           }
           load_sub<1 - SLOT>(S + 2, SUB / 2);
         }
@@ -346,24 +406,24 @@ struct StripFill {
 #pragma unroll
       for (int g2 = 0; g2 < 2; g2++) {
         const uint32_t l4 = letters_group(mwin[2 * hb + g2]);
+        const uint32_t x4 = BROW ? P::perm_bytes(rowreg, l4) : l4;
         // the next block's letters: scalar loads share lgkmcnt with the lane exchange above, so they are issued right
         // behind one group's wait and have the 4 steps to the next one to arrive
         if (J == NSB - 1 && h == 0 && g2 == 0) load_letters(q + 1, mnext);
         const int j0 = 8 * hb + 4 * g2;                    // step within the block
         if (MODE == 2 || ((MODE == 1 || MODE == 3 || MODE == 4) && PW_STRIP_ROLL_START)) {
 #pragma unroll 1
-          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, P::byte_of(l4, s));
+          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, x4, s);
         } else {
 #pragma unroll
-          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, P::byte_of(l4, s));
+          for (int s = 0; s < 4; s++) step<MODE>(kStripBlock * q + j0 + s, j0 + s, m, x4, s);
         }
       }
       mw[hb] = m;
     }
-    return true;
   }
   template <int MODE>
-  PW_FN bool block(int q) {
+  PW_FN void block(int q) {
 #pragma unroll
     for (int d = 0; d < 8; d++) mwin[d] = mnext[d];
     uint32_t mw[4];
@@ -373,11 +433,11 @@ struct StripFill {
       kb0 = (int32_t)(((uint32_t)(best > floor25 ? best : floor25) << 5) | 31u);   // an equal score later in the row loses
       kbest = kb0; ksnap = kb0;
     }
-    if (!sub_block<MODE, 0>(q, mw)) return false;
-    if (!sub_block<MODE, 1>(q, mw)) return false;
+    sub_block<MODE, 0>(q, mw);
+    sub_block<MODE, 1>(q, mw);
     if (NSB == 4) {
-      if (!sub_block<MODE, 2>(q, mw)) return false;
-      if (!sub_block<MODE, 3>(q, mw)) return false;
+      sub_block<MODE, 2>(q, mw);
+      sub_block<MODE, 3>(q, mw);
     }
 #pragma unroll
     for (int d = 0; d < 4; d++) mprev[d] = mw[d];
@@ -393,10 +453,9 @@ struct StripFill {
       best = ch ? (kb >> 5) : best;
       bestY = ch ? kStripBlock * q + (31 - (kb & 31)) - lane : bestY;
     }
-    return true;
   }
 
-  PW_FN bool run(int w_, bool cross_in_, bool cross_out_) {
+  PW_FN void run(int w_, bool cross_in_, bool cross_out_) {
     lane = P::lane();
     w = w_;
     cross_in = cross_in_; cross_out = cross_out_;
@@ -405,10 +464,18 @@ struct StripFill {
     mseq = a.arena + a.m_off;
     const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
     oc = (uint32_t)P::in_vgpr((int32_t)oseq[oi]);      // opaque: a compare known to be 8 bits wide is not folded into a byte select
+    rowreg = 0;
+    if (BROW) {
+#pragma unroll
+      for (uint32_t m = 0; m < 4; m++) rowreg |= ((uint32_t)(oc == m ? a.match : a.mismatch) & 0xffu) << (8 * m);
+    }
     w0 = 0; w1 = 0; wpend = 0; wshift = 3u - ((uint32_t)lane & 3u); wfrom = (uint32_t)((lane - 4) & 63);
     kbest = 0; mprev_q = -1; bqv = NEG; ksnap = 0; kY = a.Y + lane;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
     gP = 0; cH = NEG; cU = NEG;
+    we0 = lane - SUB;
+    wtag = (unsigned)we0 < (unsigned)SUB ? (a.epoch << 8) : 0u;
+    wm255 = (unsigned)we0 < (unsigned)SUB ? 255u : 0u;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
     // steady blocks hold no first-row / first-column cell except row 0 itself
     b0 = (a.brule == BRULE_ANY || (a.brule == BRULE_EDGE && x == 0)) ? 0 : NEG;
@@ -424,42 +491,50 @@ struct StripFill {
       uint64_t t = need ? P::fifo_load(fin + lane) : 0;
       int spins = 0;
       while (!P::all(!need || (uint32_t)(t >> 32) == tag_of(lane))) {
-        if (++spins > a.spin_limit || ((spins & 63) == 0 && P::flag_poll(a.ctl + kStripAbort) != 0u)) {
-          P::flag_set(a.ctl + kStripAbort);
-          return false;
-        }
+        if (++spins > a.spin_limit || ((spins & 63) == 0 && P::uniform((int32_t)P::flag_poll(a.ctl + kStripAbort)) != 0)) give_up();
         P::sleep();
         if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + lane) : P::fifo_poll_local(fin + lane);
       }
 #if PW_STRIP_MID
-      if (!merge_value(t, 0, 0, 2 * SUB)) return false;
+      merge_value(t, 0, 0, 2 * SUB);
 #else
-      if (!merge_value(t, 0, 0)) return false;
+      merge_value(t, 0, 0);
       load_sub<1>(1, SUB);
 #endif
     }
     stamp(2);
+    // steady: every lane holds an in-table cell on every step of the block and none its first or last one ... and the
+    // hand-overs of the block touch existing columns only: up to k0 + 63, loaded for the next block's first merge -- so the
+    // FAST hand-over needs no range check.  (The one or two blocks in front of the first last column that this leaves out run
+    // as "ending" ones, whose cells before the last column are ordinary cells too.)  Steady blocks are blocks 2 .. q_end - 1:
+    // they get a loop of their own, so that nothing another kind of block needs is carried or updated in it.
+    const int q_end = a.Y >= 2 * kStripBlock - 1 ? (a.Y - (2 * kStripBlock - 1)) / kStripBlock + 1 : 0;   // first q with k0 + 63 > Y
+    // every row of the strip is in the table (and the first two blocks' hand-overs stay below column 96)
+    const bool whole = a.Y > 128 && 64 * w + 63 <= a.X;
     for (int q = 0; q < a.nkq; q++) {
       const int k0 = kStripBlock * q;
       if (q == 2) stamp(3);
       if (q == 3) stamp(4);
-      if (k0 + kStripBlock - 1 >= a.Y && k0 - kStripBlock + kStripBlock - 1 < a.Y) stamp(6);     // first block past the steady ones
-      // steady: every lane holds an in-table cell on every step of the block and none its first or last one
-      const bool steady = k0 >= 63 && k0 + kStripBlock - 1 < a.Y;
-      const bool whole = a.Y > 64 && 64 * w + 63 <= a.X;           // every row of the strip is in the table
+      if (q >= 2 && q < q_end) {
+        for (; q < q_end; q++) {
+          if (q == 3) stamp(4);
+          block<0>(q);
+        }
+        q--;
+        stamp(6);                                                       // first block past the steady ones
+        continue;
+      }
       const bool starting = k0 < 64 && whole;
       const bool ending = k0 >= 64 && whole;
-      if (steady) { if (!block<0>(q)) return false; }
-      else if (starting && w > 0) { if (!block<4>(q)) return false; }
-      else if (starting) { if (!block<1>(q)) return false; }
-      else if (ending) { if (!block<3>(q)) return false; }
-      else { if (!block<2>(q)) return false; }
+      if (starting && w > 0) block<4>(q);
+      else if (starting) block<1>(q);
+      else if (ending) block<3>(q);
+      else block<2>(q);
     }
     flush_out(kStripBlock * a.nkq - SUB);      // the last SUB steps' cells (columns <= Y only)
     store_masks();
     stamp(5);
     finish();
-    return true;
   }
 
   // The strip's candidate for the end cell: (score desc, scan rank asc) over its rows (_std_find_optimal,

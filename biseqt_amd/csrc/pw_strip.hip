@@ -30,6 +30,9 @@ struct DevPS {
   }
   PW_FN static uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t bytes) { return __builtin_amdgcn_alignbyte(hi, lo, bytes); }
   PW_FN static uint32_t byte_of(uint32_t v, int i) { return __builtin_amdgcn_ubfe(v, 8u * (uint32_t)i, 8u); }   // folds into an SDWA byte select
+  PW_FN static int32_t sbyte_of(uint32_t v, int i) { return __builtin_amdgcn_sbfe((int32_t)v, 8u * (uint32_t)i, 8u); }   // ... with sign extension
+  // byte i of the result = byte sel.byte[i] (0 .. 3) of `row` (v_perm_b32: selector values 0 .. 3 pick from the second source)
+  PW_FN static uint32_t perm_bytes(uint32_t row, uint32_t sel) { return __builtin_amdgcn_perm(row, row, sel); }
   PW_FN static void issue_here() { __builtin_amdgcn_sched_barrier(0); }
   // 2 h + b as ONE add-with-carry whose carry-in is the comparison's lane mask (the compiler would select and shift-or)
   PW_FN static int32_t twice_plus(int32_t h, bool b) {
@@ -68,15 +71,27 @@ struct DevPS {
   // original, the late data then lands in whatever lives there next): they go to ACCUMULATION registers a[2 SLOT],
   // a[2 SLOT + 1], which this kernel uses for nothing else (gfx950: unified VGPR / AGPR file; vector memory instructions
   // can target them).  The pair is zeroed first, so "not arrived yet" reads as a granule without a tag.
+  // (the zeroing runs in EVERY lane -- call it outside the branch that picks the loading lanes -- so that a lane that
+  //  loads nothing reads as "no granule, tag 0" too: the fast hand-over compares all 64 lanes at once)
+  template <int SLOT> PW_FN static void slot_zero() {
+    static_assert(SLOT == 0 || SLOT == 1, "two hand-over slots");
+    if (SLOT == 0) asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0" ::: "memory", "a0", "a1");
+    else asm volatile("v_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0" ::: "memory", "a2", "a3");
+  }
   template <int SLOT> PW_FN static void fifo_load_async(const uint64_t* p, bool cross) {
     static_assert(SLOT == 0 || SLOT == 1, "two hand-over slots");
     if (SLOT == 0) {
-      if (cross) asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tglobal_load_dwordx2 a[0:1], %0, off sc1" :: "v"(p) : "memory", "a0", "a1");
-      else asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tglobal_load_dwordx2 a[0:1], %0, off nt" :: "v"(p) : "memory", "a0", "a1");
+      if (cross) asm volatile("global_load_dwordx2 a[0:1], %0, off sc1" :: "v"(p) : "memory", "a0", "a1");
+      else asm volatile("global_load_dwordx2 a[0:1], %0, off nt" :: "v"(p) : "memory", "a0", "a1");
     } else {
-      if (cross) asm volatile("v_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tglobal_load_dwordx2 a[2:3], %0, off sc1" :: "v"(p) : "memory", "a2", "a3");
-      else asm volatile("v_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tglobal_load_dwordx2 a[2:3], %0, off nt" :: "v"(p) : "memory", "a2", "a3");
+      if (cross) asm volatile("global_load_dwordx2 a[2:3], %0, off sc1" :: "v"(p) : "memory", "a2", "a3");
+      else asm volatile("global_load_dwordx2 a[2:3], %0, off nt" :: "v"(p) : "memory", "a2", "a3");
     }
+  }
+  // `v` into lanes 16 .. 31 of `old`, the other lanes keep theirs: ONE DPP move whose row mask enables row 1 only (no lane
+  // mask in scalar registers, no select)
+  PW_FN static int32_t row1(int32_t old, int32_t v) {
+    return __builtin_amdgcn_update_dpp(old, v, 0xe4 /* quad_perm:[0,1,2,3] */, 0x2, 0xf, false);
   }
   template <int SLOT, int N> PW_FN static uint64_t wait_vm() {
     uint32_t lo, hi;
@@ -119,6 +134,7 @@ struct DevPS {
     return v;
   }
   PW_FN static void sleep() { __builtin_amdgcn_s_sleep(1); }
+  PW_FN static void exit_wave() { __builtin_amdgcn_endpgm(); }
   PW_FN static uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }      // 100 MHz
   PW_FN static uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load((const g_u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   PW_FN static void flag_set(uint32_t* p) { __hip_atomic_store((g_u32*)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -129,7 +145,7 @@ struct DevPS {
 // flavour of a store, never whether a strip gets done: a queue nobody serves ends in the bounded waits' abort.
 PW_FN int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu); }
 
-template <bool TRACK>
+template <bool TRACK, bool BROW>
 __global__ __launch_bounds__(64) void k_fill_strip(const StripParams a) {
   const int qi = a.xcc_queue[xcc_id() & 7];
   if (qi < 0) return;
@@ -143,10 +159,12 @@ __global__ __launch_bounds__(64) void k_fill_strip(const StripParams a) {
     if (DevPS::flag_load(a.ctl + kStripAbort) != 0u) return;
     if (a.stamps != nullptr && threadIdx.x == 0) {
       a.stamps[(uint64_t)w * 8] = DevPS::clock();
-      a.stamps[(uint64_t)w * 8 + 7] = (uint64_t)xcc_id() | ((uint64_t)blockIdx.x << 8);
+      // [7]: XCC id | workgroup << 8 | HW_REG_HW_ID << 32 (wave slot, SIMD, CU, SE: which strips shared a SIMD)
+      a.stamps[(uint64_t)w * 8 + 7] = (uint64_t)xcc_id() | ((uint64_t)blockIdx.x << 8) |
+                                      ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
     }
-    StripFill<DevPS, TRACK> f(a);
-    if (!f.run(w, i == 0, i == a.run_len - 1)) return;
+    StripFill<DevPS, TRACK, BROW> f(a);
+    f.run(w, i == 0, i == a.run_len - 1);      // (an abandoned wait ends the wavefront inside)
   }
 }
 
@@ -162,13 +180,15 @@ __global__ __launch_bounds__(64) void k_trace_strip(const StripTraceParams p) {
   strip_walk<DevPS>(p, win);
 }
 
-hipError_t launch_strip_fill(const StripParams& a, bool track, int nworkers, int lds_bytes, hipStream_t st) {
+hipError_t launch_strip_fill(const StripParams& a, bool track, bool byte_rows, int nworkers, int lds_bytes, hipStream_t st) {
   // the work queue head and the abort flag start at zero
   hipError_t e = hipMemsetAsync(a.ctl, 0, 16 * sizeof(uint32_t), st);
   if (e != hipSuccess) return e;
   const dim3 grid((unsigned)nworkers), block(64);
-  if (track) hipLaunchKernelGGL((k_fill_strip<true>), grid, block, (size_t)lds_bytes, st, a);
-  else hipLaunchKernelGGL((k_fill_strip<false>), grid, block, (size_t)lds_bytes, st, a);
+  if (track && byte_rows) hipLaunchKernelGGL((k_fill_strip<true, true>), grid, block, (size_t)lds_bytes, st, a);
+  else if (track) hipLaunchKernelGGL((k_fill_strip<true, false>), grid, block, (size_t)lds_bytes, st, a);
+  else if (byte_rows) hipLaunchKernelGGL((k_fill_strip<false, true>), grid, block, (size_t)lds_bytes, st, a);
+  else hipLaunchKernelGGL((k_fill_strip<false, false>), grid, block, (size_t)lds_bytes, st, a);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_strip_finish, dim3(1), dim3(64), 0, st, a);

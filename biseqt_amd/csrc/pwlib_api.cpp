@@ -725,7 +725,10 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
       HIP_TRY(hipMemset(d_stamps, 0, (size_t)a.nstrips * 64));
       a.stamps = d_stamps;
     }
-    HIP_TRY(pw::launch_strip_fill(a, track, workers, lds_kb << 10, st));
+    // byte rows (pw_strip.h, BROW): at most 4 letters, both scores a signed byte
+    const bool byte_rows = b->L <= 4 && a.match >= -128 && a.match <= 127 && a.mismatch >= -128 && a.mismatch <= 127 &&
+                           !env_int("PWLIB_STRIP_NO_BYTE_ROWS", 0);
+    HIP_TRY(pw::launch_strip_fill(a, track, byte_rows, workers, lds_kb << 10, st));
     if (d_stamps) {
       std::vector<uint64_t> h((size_t)a.nstrips * 8);
       HIP_TRY(hipStreamSynchronize(st));

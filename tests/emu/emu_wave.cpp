@@ -107,13 +107,21 @@ struct EmuPS : EmuP {
   }
   static int32_t twice_plus(int32_t h, bool b) { return h + h + (b ? 1 : 0); }
   static uint32_t byte_of(uint32_t v, int i) { return (v >> (8 * i)) & 0xffu; }
+  static int32_t sbyte_of(uint32_t v, int i) { return (int32_t)(int8_t)((v >> (8 * i)) & 0xffu); }
+  static uint32_t perm_bytes(uint32_t row, uint32_t sel) {
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= ((row >> (8 * ((sel >> (8 * i)) & 3u))) & 0xffu) << (8 * i);
+    return r;
+  }
   static void issue_here() {}
   static uint64_t fifo_load(const uint64_t* p) { return *p; }
   static uint64_t fifo_poll(const uint64_t* p) { return *p; }
   static uint64_t fifo_poll_local(const uint64_t* p) { return *p; }
   static uint64_t fifo_load_local(const uint64_t* p) { return *p; }
   static uint64_t* slot(int s) { static uint64_t slots[2][Emu::N]; return &slots[s][Emu::self->cur]; }
+  template <int SLOT> static void slot_zero() { *slot(SLOT) = 0; }
   template <int SLOT> static void fifo_load_async(const uint64_t* p, bool) { *slot(SLOT) = *p; }
+  static int32_t row1(int32_t old, int32_t v) { const int l = Emu::self->cur; return (l >= 16 && l < 32) ? v : old; }
   template <int SLOT, int N> static uint64_t wait_vm() { return *slot(SLOT); }
   static uint32_t letters_dword(const uint8_t* m, int idx) {
     return (uint32_t)m[4 * idx] | ((uint32_t)m[4 * idx + 1] << 8) | ((uint32_t)m[4 * idx + 2] << 16) | ((uint32_t)m[4 * idx + 3] << 24);
@@ -123,6 +131,8 @@ struct EmuPS : EmuP {
   static void fifo_store(uint64_t* p, uint64_t v) { *p = v; }
   static void fifo_store_local(uint64_t* p, uint64_t v) { *p = v; }
   static void sleep() {}
+  // (an abandoned wait: the lane's fiber ends here, like the wavefront on the device)
+  static void exit_wave() { Emu* e = Emu::self; e->done[e->cur] = true; swapcontext(&e->ctx[e->cur], &e->main_ctx); }
   static uint64_t ballot(bool p) {
     Emu* e = Emu::self;
     const int l = e->cur;
@@ -322,6 +332,9 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
 
 }  // namespace
 
+int g_strip_byte_rows = 1;
+extern "C" void emu_set_strip_byte_rows(int v) { g_strip_byte_rows = v; }
+
 // Standard-mode problem through the strip pipeline: strips in index order, end-cell reduction, strip walker, fix-up.
 extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mutant, int Y, double match, double mismatch,
                                double go, double ge, unsigned epoch, int* info, double* score, char* txbuf, int txcap) {
@@ -354,11 +367,18 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
   a.spin_limit = 4;
   a.score_mul = 1.0;
   const bool track = pl.endrule != pw::END_CORNER;
+  // byte rows (pw_strip.h, BROW) under the library's admission rule: letters 0 .. 3, both scores a signed byte
+  bool brow = g_strip_byte_rows != 0 && a.match >= -128 && a.match <= 127 && a.mismatch >= -128 && a.mismatch <= 127;
+  for (int i = 0; i < X; i++) brow = brow && origin[i] < 4;
+  for (int i = 0; i < Y; i++) brow = brow && mutant[i] < 4;
   for (int w = 0; w < a.nstrips; w++) {
     Emu emu;
     bool ok = true;
-    if (track) emu.run([&]() { pw::StripFill<EmuPS, true> f(a); if (!f.run(w, (w & 1) == 0, (w & 1) != 0)) ok = false; });
-    else emu.run([&]() { pw::StripFill<EmuPS, false> f(a); if (!f.run(w, (w & 1) == 0, (w & 1) != 0)) ok = false; });
+    if (track && brow) emu.run([&]() { pw::StripFill<EmuPS, true, true> f(a); f.run(w, (w & 1) == 0, (w & 1) != 0); });
+    else if (track) emu.run([&]() { pw::StripFill<EmuPS, true, false> f(a); f.run(w, (w & 1) == 0, (w & 1) != 0); });
+    else if (brow) emu.run([&]() { pw::StripFill<EmuPS, false, true> f(a); f.run(w, (w & 1) == 0, (w & 1) != 0); });
+    else emu.run([&]() { pw::StripFill<EmuPS, false, false> f(a); f.run(w, (w & 1) == 0, (w & 1) != 0); });
+    if (ctl[pw::kStripAbort] != 0u) ok = false;
     if (!ok) return -7;
   }
   { Emu emu; emu.run([&]() { pw::strip_reduce<EmuPS>(a); }); }

@@ -27,6 +27,22 @@ t = np.fromfile(out, dtype=np.uint64).reshape(-1, 8)
 t0 = t[:, 0].min()
 us = (t[:, :7].astype(np.int64) - int(t0)) / 100.0
 xcc = (t[:, 7] & 0xff).astype(int)
+hw = (t[:, 7] >> 32).astype(np.int64)
+wg = ((t[:, 7] >> 8) & 0xffffff).astype(int)
+# HW_REG_HW_ID (gfx9 layout): wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+place = np.stack([xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15, (hw >> 4) & 3], axis=1)
+workers = {}
+for w in range(len(t)):
+    workers.setdefault(wg[w], tuple(place[w]))
+simds = {}
+for g, pl in workers.items():
+    simds.setdefault(pl, []).append(g)
+cus = {}
+for pl in simds:
+    cus.setdefault(pl[:4], []).append(pl[4])
+print('workers seen %d on %d distinct SIMDs in %d CUs; SIMDs with more than one worker: %d (max %d); workers per CU: %s'
+      % (len(workers), len(simds), len(cus), sum(1 for v in simds.values() if len(v) > 1), max(len(v) for v in simds.values()),
+         dict(zip(*np.unique([sum(len(simds[c + (s_,)]) for s_ in set(v)) for c, v in cus.items()], return_counts=True)))))
 names = ['dequeue', 'setup', 'granules seen', 'step 64', 'step 96', 'end', 'first block past the steady ones']
 print('strips %d; columns: %s (us since the first dequeue)' % (len(t), ', '.join(names)))
 for w in list(range(0, min(len(t), 12))) + list(range(124, min(len(t), 134))) + list(range(len(t) - 3, len(t))):
@@ -37,7 +53,7 @@ print('hop (granules seen, w -> w+1): median %.2f us, mean %.2f, p90 %.2f; same-
       % (np.median(d), d.mean(), np.percentile(d, 90), np.median(d[xcc[1:] == xcc[:-1]]) if (xcc[1:] == xcc[:-1]).any() else -1,
          np.median(d[xcc[1:] != xcc[:-1]]) if (xcc[1:] != xcc[:-1]).any() else -1))
 nst = (Y + 64 + 31) // 32 * 32
-first_end = (Y - 31 + 31) // 32 * 32          # first block with k0 + 31 >= Y
+first_end = ((Y - 63) // 32 + 1) * 32 if Y >= 63 else 0          # first block past the steady ones (k0 + 63 > Y)
 print('steady part (step 96 -> first end block at step %d): %.1f ns per step; end part (%d steps): median %.2f us = %.1f ns per step'
       % (first_end, 1000 * np.median(us[:, 6] - us[:, 4]) / max(1, first_end - 96), nst - first_end,
          np.median(us[:, 5] - us[:, 6]), 1000 * np.median(us[:, 5] - us[:, 6]) / max(1, nst - first_end)))

@@ -31,12 +31,12 @@ def test_strip_kernel_uses_exactly_its_four_accumulation_registers():
         B.build()
     assert codeobj.strip_kernel_violations(path) == []
     md = _md('pw_strip.o')
-    for name in ('k_fill_strip<true>', 'k_fill_strip<false>'):
+    for name in ('k_fill_strip<true, true>', 'k_fill_strip<true, false>', 'k_fill_strip<false, true>', 'k_fill_strip<false, false>'):
         k = md[name]
         assert k['agpr_count'] == 4 and k['vgpr_spill_count'] == 0 and k['private_segment_fixed_size'] == 0, (name, k)
-    # the asm sites themselves: two zeroing writes + one load per slot and flavour, two reads per wait
+    # the asm sites themselves: two zeroing writes per slot, one load per slot and flavour, two reads per wait
     dis = codeobj.disassembly(path, 'k_fill_strip')
-    assert len(dis) == 2
+    assert len(dis) == 4
     for sym, lines in dis.items():
         loads = [l for l in lines if l.startswith('global_load_dwordx2 a[')]
         assert loads and all((' sc1' in l) or (' nt' in l) for l in loads), sym
@@ -45,8 +45,8 @@ def test_strip_kernel_uses_exactly_its_four_accumulation_registers():
 
 def test_strip_checker_reports_foreign_agpr_use(monkeypatch):
     """The detector itself: an a4, an MFMA-style AGPR operand, an AGPR spill or a changed count must all be reported."""
-    good_md = {'void pw::k_fill_strip<true>(pw::StripParams)': dict(agpr_count=4, vgpr_spill_count=0, private_segment_fixed_size=0),
-               'void pw::k_fill_strip<false>(pw::StripParams)': dict(agpr_count=4, vgpr_spill_count=0, private_segment_fixed_size=0)}
+    good_md = {'void pw::k_fill_strip<%s, %s>(pw::StripParams)' % (t, b): dict(agpr_count=4, vgpr_spill_count=0, private_segment_fixed_size=0)
+               for t in ('true', 'false') for b in ('true', 'false')}
     good = ['v_accvgpr_write_b32 a0, 0', 'v_accvgpr_write_b32 a1, 0', 'global_load_dwordx2 a[0:1], v[2:3], off nt',
             'global_load_dwordx2 a[2:3], v[10:11], off sc1', 's_waitcnt vmcnt(1)', 'v_accvgpr_read_b32 v7, a3',
             'v_add_u32_e32 v1, v2, v3', 's_and_b64 s[0:1], s[2:3], exec']
@@ -61,7 +61,7 @@ def test_strip_checker_reports_foreign_agpr_use(monkeypatch):
     monkeypatch.setattr(codeobj, 'disassembly', lambda p, s=None: {'k_fill_stripILb1E': list(good)})
     for change in (dict(agpr_count=6), dict(agpr_count=0), dict(vgpr_spill_count=3), dict(private_segment_fixed_size=16)):
         md = {n: dict(k) for n, k in good_md.items()}
-        md['void pw::k_fill_strip<true>(pw::StripParams)'].update(change)
+        md['void pw::k_fill_strip<true, false>(pw::StripParams)'].update(change)
         monkeypatch.setattr(codeobj, 'kernel_metadata', lambda p, m=md: m)
         assert len(codeobj.strip_kernel_violations('x.o')) == 1, change
 

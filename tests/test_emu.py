@@ -246,11 +246,25 @@ def test_emu_strip_pipeline(oracle):
         sc = scores[trial % len(scores)]
         kw = dict(L=4, mode=0, alntype=trial % 7, match=float(sc[0]), mismatch=float(sc[1]), go=float(sc[2]), ge=float(sc[3]))
         a = oracle.solve(o, m, **kw)
-        b = emu.solve_strip(o, m, epoch=3 + trial, **kw)
+        # (both forms of the substitution score: the row's scores as 4 bytes + v_perm_b32, and compare / select)
+        b = emu.solve_strip(o, m, epoch=3 + trial, byte_rows=trial % 3 != 0, **kw)
         for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
             assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
         n += 1
     assert n == 84
+    # table widths around the thresholds of the block kinds (pw_strip.h, run(): a strip's first two blocks take the fast
+    # hand-over when Y > 128; steady blocks are those with k0 >= 64 and k0 + 63 <= Y; the rest run as ending / general ones)
+    for trial, Y in enumerate((95, 126, 127, 128, 129, 130, 158, 159, 160, 190, 191, 192, 193, 222, 223, 224, 255, 256, 287)):
+        X = 150 + 7 * (trial % 5)
+        o = rng.integers(0, 4, X).astype(np.uint8)
+        m = synth.mutate(rng, o, 0.08, 0.04, 0.3)
+        m = np.concatenate([m, rng.integers(0, 4, 300).astype(np.uint8)])[:Y]
+        sc = scores[trial % len(scores)]
+        kw = dict(L=4, mode=0, alntype=(1, 0, 3, 1, 2, 5)[trial % 6], match=float(sc[0]), mismatch=float(sc[1]), go=float(sc[2]), ge=float(sc[3]))
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve_strip(o, m, epoch=200 + trial, byte_rows=trial % 2 == 0, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
 
 
 def _random_matrix(rng, L, kind):
