@@ -88,7 +88,8 @@ def _jobs():
     jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_trace.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_trace.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_strip.o')
-    jobs.append((obj, [HIPCC] + COMMON + ['-c', os.path.join(HERE, 'pw_strip.hip'), '-o', obj],
+    # (PW_STRIP_CXXFLAGS: A/B builds of the strip kernel alone, e.g. -DPW_STRIP_LEAD=16)
+    jobs.append((obj, [HIPCC] + COMMON + os.environ.get('PW_STRIP_CXXFLAGS', '').split() + ['-c', os.path.join(HERE, 'pw_strip.hip'), '-o', obj],
                  [os.path.join(HERE, 'pw_strip.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_seeds.o')
     jobs.append((obj, [HIPCC] + COMMON + ['-Wno-unused-parameter', '-c', os.path.join(HERE, 'pw_seeds.hip'), '-o', obj],

@@ -52,7 +52,7 @@ struct StripParams {
   Result* result;            // the pair's record
   int32_t X, Y;
   int32_t nstrips, nkq;      // strips of 64 rows; blocks of 32 steps per strip (steps 0 .. Y + 63)
-  int32_t fifo_pitch;        // granules per FIFO row (>= Y + 1)
+  int32_t fifo_pitch;        // granules per FIFO row (strip_fifo_pitch(Y))
   uint32_t epoch;            // tag of this solve: granules of earlier solves never match (the buffer is never cleared)
   int32_t brule, endrule;
   int32_t match, mismatch, go, ge;
@@ -64,7 +64,7 @@ struct StripParams {
   // XCD and writes its row through to memory.  xcc_queue maps the hardware's XCC id to a queue (-1: no such XCD here).
   int32_t run_len, nq;
   int32_t xcc_queue[8];
-  uint64_t* stamps;          // tuning aid (PWLIB_STRIP_TRACE): [nstrips][8] clock stamps, or null
+  uint64_t* stamps;          // tuning aid (PWLIB_STRIP_TRACE): [nstrips][16]: clock stamps [0..6], placement [7], shader-clock counts [8 + i], or null
 };
 constexpr int kStripAbort = 8;     // index of the abort flag in StripParams::ctl
 
@@ -75,6 +75,11 @@ struct StripTraceParams {
   const int32_t* ends;       // optional explicit end cell (i, j)
   int32_t X, Y, nkq, tx_cap, gosign;
 };
+
+// Granules per FIFO row: the columns 0 .. Y and, behind them, the virtual columns a strip's lane 63 still computes in
+// its last blocks (up to 32 nkq - 64 <= Y + 31: they are written like any other, so the end blocks flush without a range
+// check) -- rounded up to whole 64-granule lines.
+PW_FN int strip_fifo_pitch(int Y) { return (Y + 1 + 32 + 63) / 64 * 64; }
 
 PW_FN uint64_t strip_mask_index(int nkq, int w, int q, int lane) {      // in dwords
   return ((uint64_t)((uint64_t)w * nkq + q) * 64 + lane) * 4;
@@ -134,9 +139,15 @@ struct StripFill {
   // the "nothing loaded" tag 0 -- so ONE comparison over all 64 lanes says whether the sub-chunk has arrived
   uint32_t wtag, wm255;       // lanes 16 .. 31: epoch << 8 and 255; else 0 and 0
   int32_t we0;                // lane - 16: this lane's column within a sub-chunk that sits in lanes 16 .. 31
+  int32_t ylim;               // 32 nkq - 64: the last column (real or virtual) a strip writes to its FIFO row
 
   PW_FN explicit StripFill(const StripParams& a_) : a(a_) {}
-  PW_FN void stamp(int i) { if (a.stamps != nullptr && lane == 0) a.stamps[(uint64_t)w * 8 + i] = P::clock(); }
+  PW_FN void stamp(int i) {
+    if (a.stamps != nullptr && lane == 0) {
+      a.stamps[(uint64_t)w * 16 + i] = P::clock();            // 100 MHz
+      a.stamps[(uint64_t)w * 16 + 8 + i] = P::cycles();       // the shader clock: what frequency the strip ran at
+    }
+  }
 
   // MODE 0  steady: every lane holds an in-table cell that is neither the first nor the last of its row
   //      1  start of a strip (steps 0 .. 63) when its rows are all in the table and the table has more than 64 columns:
@@ -261,34 +272,60 @@ struct StripFill {
 #ifndef PW_STRIP_FAST
 #define PW_STRIP_FAST 1     /* 0: every block hands over through the general code (A/B) */
 #endif
+#ifndef PW_STRIP_ALWAYS_SC1
+#define PW_STRIP_ALWAYS_SC1 1     /* FAST blocks read and write the FIFO with agent-scope operations only: one flavour, no branch per
+                                     hand-over (a taken branch costs a lone wavefront ~25 cycles; A/B: steady step 74.8 -> 73.6 ns, hops unchanged) */
+#endif
+#ifndef PW_STRIP_LEAD
+#define PW_STRIP_LEAD 8     /* FAST blocks: steps between the issue of a hand-over load and the hand-over: 8 | 12 | 16 */
+#endif
   // FAST blocks (steady ones and the first two of a strip below the first; run() admits them only when every column the
   // hand-overs of the block touch exists): the same hand-over without the range checks.
   //   load   columns c0 .. c0 + 15 into lanes 16 .. 31 of SLOT
-  template <int SLOT>
+  //          (LIM, end blocks: columns behind `ylim` are never written -- the lanes that would hold them load nothing and
+  //           expect nothing; what they put into the feeders only ever reaches virtual cells)
+  template <int SLOT, bool LIM>
   PW_FN void load_fast(int c0) const {
     P::template slot_zero<SLOT>();
-    if ((unsigned)we0 < (unsigned)SUB) P::template fifo_load_async<SLOT>(fin + (c0 + we0), cross_in);
+    const bool have = (unsigned)we0 < (unsigned)SUB && (!LIM || c0 + we0 <= ylim);
+    if (have) P::template fifo_load_async<SLOT>(fin + (c0 + we0), PW_STRIP_ALWAYS_SC1 ? true : cross_in);
   }
   //   merge  the sub-chunk whose first column is c0 (sub-chunk S1) from SLOT into the feeders; VM = vector memory operations
   //          issued after its load.  Tags are compared in all lanes at once (wtag / wm255); anything but "all there" goes
-  //          through the general code, which polls.  Lanes 16 .. 31 of the feeders are written by a DPP move with a row mask.
-  template <int SLOT, int VM>
+  //          through the polling loop.  Lanes 16 .. 31 of the feeders are written by a DPP move with a row mask.
+  template <int SLOT, int VM, bool LIM>
   PW_FN void merge_fast(int c0, int S1) {
-    const uint64_t t = P::template wait_vm<SLOT, VM>();
-    const uint32_t want = ((uint32_t)(c0 + we0) & wm255) | wtag;
-    if (!P::all((uint32_t)(t >> 32) == want)) { merge_value(t, S1, SUB); return; }
+    uint64_t t = P::template wait_vm<SLOT, VM>();
+    uint32_t want = ((uint32_t)(c0 + we0) & wm255) | wtag;
+    if (LIM) want = c0 + we0 <= ylim ? want : 0u;
+    // (the one join of the two paths is in front of the unpacking, so the fast path runs straight through)
+    if (__builtin_expect(!P::all((uint32_t)(t >> 32) == want), 0)) t = poll_sub<LIM>(t, S1);
     const int32_t pk = (int32_t)(uint32_t)t;
     const int32_t h = pk >> 1;
     const int32_t u = h + ((pk & 1) ? vge : vgego);
     cH = P::row1(cH, h); cU = P::row1(cU, u);
   }
-  //   flush  lane 63's cells of steps k0 .. k0 + 15 (lanes 48 .. 63 of gP): columns k0 - 63 .. k0 - 48, all <= Y here
+  // the granules of sub-chunk S1 for lanes 16 .. 31, polled until all of them carry their tags
+  template <bool LIM>
+  PW_FN uint64_t poll_sub(uint64_t t, int S1) {
+    const int e = SUB * S1 + we0;
+    const bool need = (unsigned)we0 < (unsigned)SUB && (!LIM || e <= ylim);
+    const uint32_t want = tag_of(e);
+    int spins = 0;
+    while (!P::all(!need || (uint32_t)(t >> 32) == want)) {
+      if (++spins > a.spin_limit || ((spins & 63) == 0 && P::uniform((int32_t)P::flag_poll(a.ctl + kStripAbort)) != 0)) give_up();
+      P::sleep();
+      if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + e) : P::fifo_poll_local(fin + e);
+    }
+    return need ? t : 0;
+  }
+  //   flush  lane 63's cells of steps k0 .. k0 + 15 (lanes 48 .. 63 of gP): columns k0 - 63 .. k0 - 48 (virtual ones behind
+  //          column Y included: the row has room for them)
   PW_FN void flush_fast(int k0) {
-    if (fout == nullptr) return;
     const int y = k0 + lane - (64 - SUB) - 63;
     if (lane >= 64 - SUB && y >= 0) {
       const uint64_t g = ((uint64_t)tag_of(y) << 32) | (uint64_t)(uint32_t)gP;
-      if (cross_out) P::fifo_store(fout + y, g);
+      if (PW_STRIP_ALWAYS_SC1 || cross_out) P::fifo_store(fout + y, g);
       else P::fifo_store_local(fout + y, g);
     }
   }
@@ -324,7 +361,7 @@ struct StripFill {
   }
   PW_FN void load_letters(int q, uint32_t (&win)[8]) const {        // m[32 q .. 32 q + 31], dwords clamped to the frame
     const int last = a.Y > 0 ? (a.Y - 1) >> 2 : 0;
-    if (8 * q + 7 <= last) { P::letters_x8(mseq, 8 * q, win); return; }      // one 32-byte scalar load
+    if (__builtin_expect(8 * q + 7 <= last, 1)) { P::letters_x8(mseq, 8 * q, win); return; }      // one 32-byte scalar load
 #pragma unroll
     for (int d = 0; d < 8; d++) {
       const int idx = 8 * q + d;
@@ -350,13 +387,16 @@ struct StripFill {
   // load -- that mask store and the FIFO store in front of this sub-chunk (vmcnt(0 .. 2)); everything older has had SUB
   // steps to complete.  (On gfx9-family targets loads and stores share one counter, so a wait for "everything" drains the
   // stores: ~1.2 us, once per hand-over, was the cost of not counting.)
-  template <int MODE, int J>
+  template <int MODE, int J, bool NOIN>
   PW_FN void sub_block(int q, uint32_t (&mw)[4]) {
     const int S = NSB * q + J;
     const int k0 = kStripBlock * q + SUB * J;
     constexpr int SLOT = (J & 1) ? 0 : 1;                // sub-chunk S + 1: odd for even J
-    constexpr bool FAST = (MODE == 0 || MODE == 4) && !PW_STRIP_MID && PW_STRIP_FAST;
-    if (fin == nullptr) {
+    constexpr bool FAST = (MODE == 0 || MODE == 3 || MODE == 4) && !PW_STRIP_MID && PW_STRIP_FAST;
+    constexpr bool LIM = MODE == 3;
+    // (FAST blocks know at compile time whether the strip has a row above it -- NOIN: the first strip -- and every strip has
+    //  a row to write: no pointer is looked at per hand-over)
+    if (FAST ? NOIN : fin == nullptr) {
       // no row above: "no predecessor" keeps entering the feeders where the granules would (the shift fills with zeros)
       if (FAST) { cH = P::row1(cH, NEG); cU = P::row1(cU, NEG); }
       else {
@@ -366,9 +406,15 @@ struct StripFill {
     }
 #if !PW_STRIP_MID
     else if (FAST) {
-      // (steady blocks: q >= 2, so the mask store of block q - 1 always sits behind the load that J = 1 waits for)
-      if ((J & 1) && (MODE == 0 || q > 0)) merge_fast<SLOT, 1>(k0 + SUB, S + 1);
-      else merge_fast<SLOT, 0>(k0 + SUB, S + 1);
+      // what was issued behind the load that this hand-over waits for: the mask store of block q - 1 in front of J = 1
+      // (steady blocks: q >= 2, there always is one) and, when the load went out at the very start of the previous
+      // sub-block (PW_STRIP_LEAD 16), the FIFO store of that sub-block
+      const bool mstore = (J & 1) && (MODE != 4 || q > 0);
+      const bool fstore = PW_STRIP_LEAD == 16 && MODE != 4;
+      if (mstore && fstore) merge_fast<SLOT, 2, LIM>(k0 + SUB, S + 1);
+      else if (mstore || fstore) merge_fast<SLOT, 1, LIM>(k0 + SUB, S + 1);
+      else merge_fast<SLOT, 0, LIM>(k0 + SUB, S + 1);
+      if (PW_STRIP_LEAD == 16) load_fast<1 - SLOT, LIM>(SUB * (S + 2));
     }
     else {
       // J odd: the mask store of block q - 1 was issued behind the load (there is none in front of block 0)
@@ -377,7 +423,7 @@ struct StripFill {
     }
 #endif
     bool flushed = false;
-    if (FAST) { if (MODE == 0) flush_fast(k0 - SUB); }   // (MODE 4: steps 0 .. 47 hold no cell of lane 63)
+    if (FAST) { if (MODE != 4) flush_fast(k0 - SUB); }   // (MODE 4: steps 0 .. 47 hold no cell of lane 63)
     else flushed = flush_out(k0 - SUB);
     (void)flushed;
 #pragma unroll
@@ -385,10 +431,8 @@ struct StripFill {
       const int hb = J * (SUB / 8) + h;                  // 8-step group within the block
       if (h == SUB / 16) {
 #if !PW_STRIP_MID
-        if (fin != nullptr) {
-          if (FAST) load_fast<1 - SLOT>(SUB * (S + 2));
-          else load_sub<1 - SLOT>(S + 2, SUB);
-        }
+        if (FAST) { if (!NOIN && PW_STRIP_LEAD == 8) load_fast<1 - SLOT, LIM>(SUB * (S + 2)); }
+        else if (fin != nullptr) load_sub<1 - SLOT>(S + 2, SUB);
 #else
         if (fin != nullptr) {
           if (S >= 1) {                                  // (run() put sub-chunks 0 and 1 into the feeders)
@@ -405,6 +449,7 @@ struct StripFill {
       uint32_t m = 0;
 #pragma unroll
       for (int g2 = 0; g2 < 2; g2++) {
+        if (FAST && !NOIN && PW_STRIP_LEAD == 12 && h == 0 && g2 == 1) load_fast<1 - SLOT, LIM>(SUB * (S + 2));
         const uint32_t l4 = letters_group(mwin[2 * hb + g2]);
         const uint32_t x4 = BROW ? P::perm_bytes(rowreg, l4) : l4;
         // the next block's letters: scalar loads share lgkmcnt with the lane exchange above, so they are issued right
@@ -422,7 +467,7 @@ struct StripFill {
       mw[hb] = m;
     }
   }
-  template <int MODE>
+  template <int MODE, bool NOIN = false>
   PW_FN void block(int q) {
 #pragma unroll
     for (int d = 0; d < 8; d++) mwin[d] = mnext[d];
@@ -433,11 +478,11 @@ struct StripFill {
       kb0 = (int32_t)(((uint32_t)(best > floor25 ? best : floor25) << 5) | 31u);   // an equal score later in the row loses
       kbest = kb0; ksnap = kb0;
     }
-    sub_block<MODE, 0>(q, mw);
-    sub_block<MODE, 1>(q, mw);
+    sub_block<MODE, 0, NOIN>(q, mw);
+    sub_block<MODE, 1, NOIN>(q, mw);
     if (NSB == 4) {
-      sub_block<MODE, 2>(q, mw);
-      sub_block<MODE, 3>(q, mw);
+      sub_block<MODE, 2, NOIN>(q, mw);
+      sub_block<MODE, 3, NOIN>(q, mw);
     }
 #pragma unroll
     for (int d = 0; d < 4; d++) mprev[d] = mw[d];
@@ -474,6 +519,7 @@ struct StripFill {
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
     gP = 0; cH = NEG; cU = NEG;
     we0 = lane - SUB;
+    ylim = kStripBlock * a.nkq - 64;
     wtag = (unsigned)we0 < (unsigned)SUB ? (a.epoch << 8) : 0u;
     wm255 = (unsigned)we0 < (unsigned)SUB ? 255u : 0u;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
@@ -482,7 +528,8 @@ struct StripFill {
     // ... and the first cell of a row (y == 0): the table edge, or the origin for row 0
     bfirst = (a.brule == BRULE_ANY || a.brule == BRULE_EDGE || x == 0) ? 0 : NEG;
     fin = w > 0 ? a.fifo + (uint64_t)(w - 1) * (uint64_t)a.fifo_pitch : nullptr;
-    fout = w + 1 < a.nstrips ? a.fifo + (uint64_t)w * (uint64_t)a.fifo_pitch : nullptr;
+    // (the last strip writes its row too -- the FIFO has a row per strip -- and nobody reads it)
+    fout = a.fifo + (uint64_t)w * (uint64_t)a.fifo_pitch;
     load_letters(0, mnext);
     stamp(1);
     if (fin != nullptr) {
@@ -503,12 +550,15 @@ struct StripFill {
 #endif
     }
     stamp(2);
-    // steady: every lane holds an in-table cell on every step of the block and none its first or last one ... and the
-    // hand-overs of the block touch existing columns only: up to k0 + 63, loaded for the next block's first merge -- so the
-    // FAST hand-over needs no range check.  (The one or two blocks in front of the first last column that this leaves out run
-    // as "ending" ones, whose cells before the last column are ordinary cells too.)  Steady blocks are blocks 2 .. q_end - 1:
-    // they get a loop of their own, so that nothing another kind of block needs is carried or updated in it.
-    const int q_end = a.Y >= 2 * kStripBlock - 1 ? (a.Y - (2 * kStripBlock - 1)) / kStripBlock + 1 : 0;   // first q with k0 + 63 > Y
+    // steady: every lane holds an in-table cell on every step of the block and none its first or last one: blocks
+    // 2 .. q_end - 1.  They get a loop of their own, so that nothing another kind of block needs is carried or updated in it.
+    // (The columns their hand-overs touch, up to k0 + 63, are all written by the strip above: k0 + 31 < Y <= ylim - ... see
+    // strip_fifo_pitch; the end blocks limit their hand-overs to `ylim`.)
+    // ... blocks q with k0 + 31 < Y whose hand-overs stay within the columns the strip above writes: k0 + 63 <= ylim
+    const int q_last_cell = a.Y >= kStripBlock ? (a.Y - kStripBlock) / kStripBlock + 1 : 0;     // first q with k0 + 31 >= Y
+    // (... and only in tables of more than 128 columns, where the strip above -- all of whose rows are in the table -- writes
+    //  its virtual columns too; narrower tables run on the general code throughout)
+    const int q_end = a.Y > 128 ? (q_last_cell < a.nkq - 3 ? q_last_cell : a.nkq - 3) : 0;
     // every row of the strip is in the table (and the first two blocks' hand-overs stay below column 96)
     const bool whole = a.Y > 128 && 64 * w + 63 <= a.X;
     for (int q = 0; q < a.nkq; q++) {
@@ -516,9 +566,13 @@ struct StripFill {
       if (q == 2) stamp(3);
       if (q == 3) stamp(4);
       if (q >= 2 && q < q_end) {
-        for (; q < q_end; q++) {
-          if (q == 3) stamp(4);
-          block<0>(q);
+        if (w == 0) {
+          for (; q < q_end; q++) block<0, true>(q);
+        } else {
+          for (; q < q_end; q++) {
+            if (__builtin_expect(a.stamps != nullptr, 0) && q == 3) stamp(4);
+            block<0, false>(q);
+          }
         }
         q--;
         stamp(6);                                                       // first block past the steady ones
@@ -528,10 +582,14 @@ struct StripFill {
       const bool ending = k0 >= 64 && whole;
       if (starting && w > 0) block<4>(q);
       else if (starting) block<1>(q);
-      else if (ending) block<3>(q);
+      else if (ending && w > 0) block<3>(q);
+      else if (ending) block<3, true>(q);
       else block<2>(q);
     }
-    flush_out(kStripBlock * a.nkq - SUB);      // the last SUB steps' cells (columns <= Y only)
+    // the last SUB steps' cells: a whole strip writes the virtual columns too (the end blocks of the strip below, whole as
+    // well, expect every column up to `ylim`), any other one the columns up to Y
+    if (whole && PW_STRIP_FAST) flush_fast(kStripBlock * a.nkq - SUB);
+    else flush_out(kStripBlock * a.nkq - SUB);
     store_masks();
     stamp(5);
     finish();

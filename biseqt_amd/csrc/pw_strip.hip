@@ -136,6 +136,7 @@ struct DevPS {
   PW_FN static void sleep() { __builtin_amdgcn_s_sleep(1); }
   PW_FN static void exit_wave() { __builtin_amdgcn_endpgm(); }
   PW_FN static uint64_t clock() { return __builtin_amdgcn_s_memrealtime(); }      // 100 MHz
+  PW_FN static uint64_t cycles() { return __builtin_amdgcn_s_memtime(); }         // shader clock
   PW_FN static uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load((const g_u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   PW_FN static void flag_set(uint32_t* p) { __hip_atomic_store((g_u32*)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
   PW_FN static int32_t in_vgpr(int32_t v) { asm volatile("" : "+v"(v)); return v; }
@@ -158,9 +159,9 @@ __global__ __launch_bounds__(64) void k_fill_strip(const StripParams a) {
     if (w >= a.nstrips) return;
     if (DevPS::flag_load(a.ctl + kStripAbort) != 0u) return;
     if (a.stamps != nullptr && threadIdx.x == 0) {
-      a.stamps[(uint64_t)w * 8] = DevPS::clock();
+      a.stamps[(uint64_t)w * 16] = DevPS::clock();
       // [7]: XCC id | workgroup << 8 | HW_REG_HW_ID << 32 (wave slot, SIMD, CU, SE: which strips shared a SIMD)
-      a.stamps[(uint64_t)w * 8 + 7] = (uint64_t)xcc_id() | ((uint64_t)blockIdx.x << 8) |
+      a.stamps[(uint64_t)w * 16 + 7] = (uint64_t)xcc_id() | ((uint64_t)blockIdx.x << 8) |
                                       ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32);
     }
     StripFill<DevPS, TRACK, BROW> f(a);

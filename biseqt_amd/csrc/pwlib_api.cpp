@@ -500,7 +500,7 @@ int batch_plan(pw_batch* b) {
       mask_words += (uint64_t)nstrips * nkq * 64 * 4;
       d.h_off = h_elems;
       b->strips.push_back(k);
-      b->fifo_bytes = std::max<size_t>(b->fifo_bytes, (size_t)nstrips * (size_t)((d.Y + 1 + 63) / 64 * 64) * 8);
+      b->fifo_bytes = std::max<size_t>(b->fifo_bytes, (size_t)nstrips * (size_t)pw::strip_fifo_pitch(d.Y) * 8);
       continue;
     }
     // a few pairs with bands wider than a wavefront holds, not served by the strips (f64 scores, a substitution matrix,
@@ -703,7 +703,7 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
     a.result = b->d_results + k;
     a.X = d.X; a.Y = d.Y;
     a.nstrips = (d.X + 1 + 63) / 64; a.nkq = (d.Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
-    a.fifo_pitch = (d.Y + 1 + 63) / 64 * 64;
+    a.fifo_pitch = pw::strip_fifo_pitch(d.Y);
     uint32_t e = g_strip_epoch.fetch_add(1) & 0xffffffu;          // 24 bits: the tag's other 8 are the column's low bits
     if (e == 0) e = g_strip_epoch.fetch_add(1) & 0xffffffu;
     a.epoch = e;
@@ -716,13 +716,13 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
     if (a.nq <= 0) return fail("could not determine the XCDs of the device");
     a.run_len = std::max(1, env_int("PWLIB_STRIP_RUN", std::max(1, workers / a.nq)));
     const bool track = b->endrule != pw::END_CORNER;
-    // tuning aid: PWLIB_STRIP_TRACE=<file> dumps per-strip clock stamps (100 MHz) of the first strip pair: dequeue, set-up
+    // tuning aid: PWLIB_STRIP_TRACE=<file> dumps per-strip clock stamps (100 MHz; [8 + i]: shader-clock counts at the same points) of the first strip pair: dequeue, set-up
     // done, first granules seen, steps 64 / 96 reached, end; [7] = XCC id | workgroup << 8
     const char* trace = getenv("PWLIB_STRIP_TRACE");
     uint64_t* d_stamps = nullptr;
     if (trace && *trace && q == 1) {
-      HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)a.nstrips * 64));
-      HIP_TRY(hipMemset(d_stamps, 0, (size_t)a.nstrips * 64));
+      HIP_TRY(hipMalloc((void**)&d_stamps, (size_t)a.nstrips * 128));
+      HIP_TRY(hipMemset(d_stamps, 0, (size_t)a.nstrips * 128));
       a.stamps = d_stamps;
     }
     // byte rows (pw_strip.h, BROW): at most 4 letters, both scores a signed byte
@@ -730,7 +730,7 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
                            !env_int("PWLIB_STRIP_NO_BYTE_ROWS", 0);
     HIP_TRY(pw::launch_strip_fill(a, track, byte_rows, workers, lds_kb << 10, st));
     if (d_stamps) {
-      std::vector<uint64_t> h((size_t)a.nstrips * 8);
+      std::vector<uint64_t> h((size_t)a.nstrips * 16);
       HIP_TRY(hipStreamSynchronize(st));
       HIP_TRY(hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost));
       (void)hipFree(d_stamps);

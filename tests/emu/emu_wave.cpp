@@ -146,6 +146,7 @@ struct EmuPS : EmuP {
   }
   static void wave_sync() { Emu* e = Emu::self; (void)e->exchange(0, e->cur, 0); }
   static uint64_t clock() { return 0; }
+  static uint64_t cycles() { return 0; }
   static int32_t in_vgpr(int32_t v) { return v; }
   static uint32_t flag_load(const uint32_t* p) { return *p; }
   static void flag_set(uint32_t* p) { *p = 1u; }
@@ -353,7 +354,7 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
   a.X = X; a.Y = Y;
   a.nstrips = (X + 1 + 63) / 64;
   a.nkq = (Y + 64 + pw::kStripBlock - 1) / pw::kStripBlock;
-  a.fifo_pitch = (Y + 1 + 63) / 64 * 64;
+  a.fifo_pitch = pw::strip_fifo_pitch(Y);
   std::vector<uint64_t> fifo((size_t)a.nstrips * a.fifo_pitch, 0x00000000deadbeefull);   // stale granules of "earlier solves"
   for (size_t i = 0; i < fifo.size(); i += 3) fifo[i] = ((uint64_t)(((epoch - 1) << 8) | (i & 0xffu)) << 32) | 12345u;
   std::vector<uint32_t> masks((size_t)a.nstrips * a.nkq * 64 * 4, 0xdeadbeefu);

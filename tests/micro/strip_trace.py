@@ -23,7 +23,7 @@ with BatchAligner([(o, m)], alnmode=0, alntype=1, alphabet_len=4, match_score=1,
     b.solve(); b.sync()
     b.solve(); b.sync()
     print('fill %.3f ms' % b.fill_ms())
-t = np.fromfile(out, dtype=np.uint64).reshape(-1, 8)
+t = np.fromfile(out, dtype=np.uint64).reshape(-1, 16)
 t0 = t[:, 0].min()
 us = (t[:, :7].astype(np.int64) - int(t0)) / 100.0
 xcc = (t[:, 7] & 0xff).astype(int)
@@ -57,5 +57,16 @@ first_end = ((Y - 63) // 32 + 1) * 32 if Y >= 63 else 0          # first block p
 print('steady part (step 96 -> first end block at step %d): %.1f ns per step; end part (%d steps): median %.2f us = %.1f ns per step'
       % (first_end, 1000 * np.median(us[:, 6] - us[:, 4]) / max(1, first_end - 96), nst - first_end,
          np.median(us[:, 5] - us[:, 6]), 1000 * np.median(us[:, 5] - us[:, 6]) / max(1, nst - first_end)))
+# the shader clock each strip ran at: counts between "granules seen" [2] and "end" [5] over the 100 MHz time between them
+cyc = (t[:, 13].astype(np.int64) - t[:, 10].astype(np.int64)).astype(np.float64)
+dur = (t[:, 5].astype(np.int64) - t[:, 2].astype(np.int64)).astype(np.float64) / 100.0        # us
+ok = dur > 0
+mhz = cyc[ok] / dur[ok]
+ws = np.nonzero(ok)[0]
+print('shader clock per strip (counts / time, MHz): strip 0 %.0f, median %.0f, min %.0f, max %.0f; strips %s: %s'
+      % (mhz[0], np.median(mhz), mhz.min(), mhz.max(), [int(ws[i]) for i in (len(ws) // 4, len(ws) // 2, -1)],
+         ['%.0f' % mhz[i] for i in (len(ws) // 4, len(ws) // 2, -1)]))
+print('strip duration (granules seen -> end, us): strip 0 %.0f, strip %d %.0f, last %.0f; in shader cycles per step: %.1f, %.1f, %.1f'
+      % (dur[0], len(dur) // 2, dur[len(dur) // 2], dur[-1], cyc[0] / (Y + 64), cyc[len(dur) // 2] / (Y + 64), cyc[-1] / (Y + 64)))
 print('granules seen -> step 64: median %.2f us; step 64 -> 96: %.2f us; strip total: %.2f us'
       % (np.median(us[:, 3] - us[:, 2]), np.median(us[:, 4] - us[:, 3]), np.median(us[:, 5] - us[:, 2])))
