@@ -95,15 +95,19 @@ struct StripFill {
 #ifndef PW_STRIP_ROLL_START
 #define PW_STRIP_ROLL_START 0     /* 1: steps 0 .. 63 as a rolled loop (smaller code) */
 #endif
-#ifndef PW_STRIP_MID
-#define PW_STRIP_MID 0     /* 1: hand-over in the middle of a sub-chunk (A/B: slower) */
+#ifndef PW_STRIP_AHEAD
+#define PW_STRIP_AHEAD 0    /* steps between a sub-chunk's entry into the feeders and lane 0's first use of it: 0 (it enters lanes
+                               0 .. 15 on the step that needs it) | 16 (round 2: lanes 16 .. 31, a sub-chunk early -- and every
+                               strip trailing the one above by 16 columns more) */
 #endif
 #ifndef PW_STRIP_SUB
 #define PW_STRIP_SUB 16    /* measured: 16 -> 33.9 ms, 8 -> 35.8 ms on config 3 (one wait for memory per hand-off) */
 #endif
   static constexpr int SUB = PW_STRIP_SUB;         // FIFO granules per hand-off (one store / one load of SUB lanes)
   static constexpr int NSB = kStripBlock / SUB;    // hand-offs per block
-  static_assert(SUB == 16, "hand-off size (the hand-over sits in the middle of a sub-chunk)");
+  static constexpr int AH = PW_STRIP_AHEAD;        // feeder lanes AH .. AH + 15 take a sub-chunk
+  static_assert(AH == 0 || AH == SUB, "feeder look-ahead");
+  static_assert(SUB == 16, "hand-off size");
   const StripParams& a;
   int lane, w, x;
   // per lane: the cell computed last (H, what it offers downwards / rightwards), the diagonal predecessor of the
@@ -135,10 +139,10 @@ struct StripFill {
   const uint64_t* fin;        // the FIFO row of the strip above or null
   bool cross_out;             // the strip below runs on another XCD: write the row through to memory
   bool cross_in;              // the strip above ran on another XCD: read its row from memory, not from this XCD's L2
-  // per-lane constants of the fast hand-over (FAST blocks): lanes 16 .. 31 expect the tag (epoch, column), every other lane
+  // per-lane constants of the fast hand-over (FAST blocks): lanes AH .. AH + 15 expect the tag (epoch, column), every other lane
   // the "nothing loaded" tag 0 -- so ONE comparison over all 64 lanes says whether the sub-chunk has arrived
-  uint32_t wtag, wm255;       // lanes 16 .. 31: epoch << 8 and 255; else 0 and 0
-  int32_t we0;                // lane - 16: this lane's column within a sub-chunk that sits in lanes 16 .. 31
+  uint32_t wtag, wm255;       // lanes AH .. AH + 15: epoch << 8 and 255; else 0 and 0
+  int32_t we0;                // lane - AH: this lane's column within a sub-chunk that sits in lanes AH .. AH + 15
   int32_t ylim;               // 32 nkq - 64: the last column (real or virtual) a strip writes to its FIFO row
 
   PW_FN explicit StripFill(const StripParams& a_) : a(a_) {}
@@ -281,7 +285,7 @@ struct StripFill {
 #endif
   // FAST blocks (steady ones and the first two of a strip below the first; run() admits them only when every column the
   // hand-overs of the block touch exists): the same hand-over without the range checks.
-  //   load   columns c0 .. c0 + 15 into lanes 16 .. 31 of SLOT
+  //   load   columns c0 .. c0 + 15 into lanes AH .. AH + 15 of SLOT
   //          (LIM, end blocks: columns behind `ylim` are never written -- the lanes that would hold them load nothing and
   //           expect nothing; what they put into the feeders only ever reaches virtual cells)
   template <int SLOT, bool LIM>
@@ -292,7 +296,7 @@ struct StripFill {
   }
   //   merge  the sub-chunk whose first column is c0 (sub-chunk S1) from SLOT into the feeders; VM = vector memory operations
   //          issued after its load.  Tags are compared in all lanes at once (wtag / wm255); anything but "all there" goes
-  //          through the polling loop.  Lanes 16 .. 31 of the feeders are written by a DPP move with a row mask.
+  //          through the polling loop.  Lanes AH .. AH + 15 of the feeders are written by a DPP move with a row mask.
   template <int SLOT, int VM, bool LIM>
   PW_FN void merge_fast(int c0, int S1) {
     uint64_t t = P::template wait_vm<SLOT, VM>();
@@ -303,9 +307,9 @@ struct StripFill {
     const int32_t pk = (int32_t)(uint32_t)t;
     const int32_t h = pk >> 1;
     const int32_t u = h + ((pk & 1) ? vge : vgego);
-    cH = P::row1(cH, h); cU = P::row1(cU, u);
+    cH = P::template rowmov<AH / SUB>(cH, h); cU = P::template rowmov<AH / SUB>(cU, u);
   }
-  // the granules of sub-chunk S1 for lanes 16 .. 31, polled until all of them carry their tags
+  // the granules of sub-chunk S1 for lanes AH .. AH + 15, polled until all of them carry their tags
   template <bool LIM>
   PW_FN uint64_t poll_sub(uint64_t t, int S1) {
     const int e = SUB * S1 + we0;
@@ -390,38 +394,38 @@ struct StripFill {
   template <int MODE, int J, bool NOIN>
   PW_FN void sub_block(int q, uint32_t (&mw)[4]) {
     const int S = NSB * q + J;
+    const int SM = S + AH / SUB;                          // the sub-chunk that enters the feeders here
     const int k0 = kStripBlock * q + SUB * J;
-    constexpr int SLOT = (J & 1) ? 0 : 1;                // sub-chunk S + 1: odd for even J
-    constexpr bool FAST = (MODE == 0 || MODE == 3 || MODE == 4) && !PW_STRIP_MID && PW_STRIP_FAST;
+    constexpr int SLOT = (J & 1) ? 0 : 1;                // its hand-over slot
+    constexpr bool FAST = (MODE == 0 || MODE == 3 || MODE == 4) && PW_STRIP_FAST;
     constexpr bool LIM = MODE == 3;
     // (FAST blocks know at compile time whether the strip has a row above it -- NOIN: the first strip -- and every strip has
     //  a row to write: no pointer is looked at per hand-over)
     if (FAST ? NOIN : fin == nullptr) {
       // no row above: "no predecessor" keeps entering the feeders where the granules would (the shift fills with zeros)
-      if (FAST) { cH = P::row1(cH, NEG); cU = P::row1(cU, NEG); }
+      if (FAST) { cH = P::template rowmov<AH / SUB>(cH, NEG); cU = P::template rowmov<AH / SUB>(cU, NEG); }
       else {
-        const bool mine = lane >= SUB && lane < 2 * SUB;
+        const bool mine = lane >= AH && lane < AH + SUB;
         cH = mine ? NEG : cH; cU = mine ? NEG : cU;
       }
     }
-#if !PW_STRIP_MID
     else if (FAST) {
       // what was issued behind the load that this hand-over waits for: the mask store of block q - 1 in front of J = 1
       // (steady blocks: q >= 2, there always is one) and, when the load went out at the very start of the previous
       // sub-block (PW_STRIP_LEAD 16), the FIFO store of that sub-block
       const bool mstore = (J & 1) && (MODE != 4 || q > 0);
       const bool fstore = PW_STRIP_LEAD == 16 && MODE != 4;
-      if (mstore && fstore) merge_fast<SLOT, 2, LIM>(k0 + SUB, S + 1);
-      else if (mstore || fstore) merge_fast<SLOT, 1, LIM>(k0 + SUB, S + 1);
-      else merge_fast<SLOT, 0, LIM>(k0 + SUB, S + 1);
-      if (PW_STRIP_LEAD == 16) load_fast<1 - SLOT, LIM>(SUB * (S + 2));
+      if (mstore && fstore) merge_fast<SLOT, 2, LIM>(SUB * SM, SM);
+      else if (mstore || fstore) merge_fast<SLOT, 1, LIM>(SUB * SM, SM);
+      else merge_fast<SLOT, 0, LIM>(SUB * SM, SM);
+      if (PW_STRIP_LEAD == 16) load_fast<1 - SLOT, LIM>(SUB * (SM + 1));
     }
     else {
       // J odd: the mask store of block q - 1 was issued behind the load (there is none in front of block 0)
       const uint64_t t = ((J & 1) && q > 0) ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>();
-      merge_value(t, S + 1, SUB);
+      merge_value(t, SM, AH);
     }
-#endif
+    if (AH == 0 && MODE != 0 && MODE != 3 && J == 0 && q == 0) stamp(2);       // the first granules are in
     bool flushed = false;
     if (FAST) { if (MODE != 4) flush_fast(k0 - SUB); }   // (MODE 4: steps 0 .. 47 hold no cell of lane 63)
     else flushed = flush_out(k0 - SUB);
@@ -430,26 +434,14 @@ struct StripFill {
     for (int h = 0; h < SUB / 8; h++) {                  // one mask dword per 8 steps
       const int hb = J * (SUB / 8) + h;                  // 8-step group within the block
       if (h == SUB / 16) {
-#if !PW_STRIP_MID
-        if (FAST) { if (!NOIN && PW_STRIP_LEAD == 8) load_fast<1 - SLOT, LIM>(SUB * (S + 2)); }
-        else if (fin != nullptr) load_sub<1 - SLOT>(S + 2, SUB);
-#else
-        if (fin != nullptr) {
-          if (S >= 1) {                                  // (run() put sub-chunks 0 and 1 into the feeders)
-            const int younger = (((J & 1) && q > 0) ? 1 : 0) + (flushed ? 1 : 0);
-            const uint64_t t = younger == 2 ? P::template wait_vm<SLOT, 2>()
-                                            : (younger == 1 ? P::template wait_vm<SLOT, 1>() : P::template wait_vm<SLOT, 0>());
-            merge_value(t, S + 1, SUB / 2);
-          }
-          load_sub<1 - SLOT>(S + 2, SUB / 2);
-        }
-#endif
+        if (FAST) { if (!NOIN && PW_STRIP_LEAD == 8) load_fast<1 - SLOT, LIM>(SUB * (SM + 1)); }
+        else if (fin != nullptr) load_sub<1 - SLOT>(SM + 1, AH);
         if (J == 0) store_masks();
       }
       uint32_t m = 0;
 #pragma unroll
       for (int g2 = 0; g2 < 2; g2++) {
-        if (FAST && !NOIN && PW_STRIP_LEAD == 12 && h == 0 && g2 == 1) load_fast<1 - SLOT, LIM>(SUB * (S + 2));
+        if (FAST && !NOIN && PW_STRIP_LEAD == 12 && h == 0 && g2 == 1) load_fast<1 - SLOT, LIM>(SUB * (SM + 1));
         const uint32_t l4 = letters_group(mwin[2 * hb + g2]);
         const uint32_t x4 = BROW ? P::perm_bytes(rowreg, l4) : l4;
         // the next block's letters: scalar loads share lgkmcnt with the lane exchange above, so they are issued right
@@ -518,7 +510,7 @@ struct StripFill {
     kbest = 0; mprev_q = -1; bqv = NEG; ksnap = 0; kY = a.Y + lane;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
     gP = 0; cH = NEG; cU = NEG;
-    we0 = lane - SUB;
+    we0 = lane - AH;
     ylim = kStripBlock * a.nkq - 64;
     wtag = (unsigned)we0 < (unsigned)SUB ? (a.epoch << 8) : 0u;
     wm255 = (unsigned)we0 < (unsigned)SUB ? 255u : 0u;
@@ -533,23 +525,24 @@ struct StripFill {
     load_letters(0, mnext);
     stamp(1);
     if (fin != nullptr) {
-      // sub-chunks 0 and 1 in ONE poll (granule = lane): once both are there they go straight into the feeders
-      const bool need = lane < 2 * SUB && lane <= a.Y;
-      uint64_t t = need ? P::fifo_load(fin + lane) : 0;
-      int spins = 0;
-      while (!P::all(!need || (uint32_t)(t >> 32) == tag_of(lane))) {
-        if (++spins > a.spin_limit || ((spins & 63) == 0 && P::uniform((int32_t)P::flag_poll(a.ctl + kStripAbort)) != 0)) give_up();
-        P::sleep();
-        if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + lane) : P::fifo_poll_local(fin + lane);
+      if (AH == 0) {
+        // the first hand-over (block 0) waits for sub-chunk 0 like any other
+        load_sub<1>(0, 0);
+      } else {
+        // sub-chunks 0 and 1 in ONE poll (granule = lane): once both are there they go straight into the feeders
+        const bool need = lane < 2 * SUB && lane <= a.Y;
+        uint64_t t = need ? P::fifo_load(fin + lane) : 0;
+        int spins = 0;
+        while (!P::all(!need || (uint32_t)(t >> 32) == tag_of(lane))) {
+          if (++spins > a.spin_limit || ((spins & 63) == 0 && P::uniform((int32_t)P::flag_poll(a.ctl + kStripAbort)) != 0)) give_up();
+          P::sleep();
+          if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + lane) : P::fifo_poll_local(fin + lane);
+        }
+        merge_value(t, 0, 0);
+        load_sub<1>(1, SUB);
       }
-#if PW_STRIP_MID
-      merge_value(t, 0, 0, 2 * SUB);
-#else
-      merge_value(t, 0, 0);
-      load_sub<1>(1, SUB);
-#endif
     }
-    stamp(2);
+    if (AH != 0) stamp(2);
     // steady: every lane holds an in-table cell on every step of the block and none its first or last one: blocks
     // 2 .. q_end - 1.  They get a loop of their own, so that nothing another kind of block needs is carried or updated in it.
     // (The columns their hand-overs touch, up to k0 + 63, are all written by the strip above: k0 + 31 < Y <= ylim - ... see

@@ -88,10 +88,10 @@ struct DevPS {
       else asm volatile("global_load_dwordx2 a[2:3], %0, off nt" :: "v"(p) : "memory", "a2", "a3");
     }
   }
-  // `v` into lanes 16 .. 31 of `old`, the other lanes keep theirs: ONE DPP move whose row mask enables row 1 only (no lane
-  // mask in scalar registers, no select)
-  PW_FN static int32_t row1(int32_t old, int32_t v) {
-    return __builtin_amdgcn_update_dpp(old, v, 0xe4 /* quad_perm:[0,1,2,3] */, 0x2, 0xf, false);
+  // `v` into lanes 16 ROW .. 16 ROW + 15 of `old`, the other lanes keep theirs: ONE DPP move whose row mask enables that
+  // row only (no lane mask in scalar registers, no select)
+  template <int ROW> PW_FN static int32_t rowmov(int32_t old, int32_t v) {
+    return __builtin_amdgcn_update_dpp(old, v, 0xe4 /* quad_perm:[0,1,2,3] */, 1 << ROW, 0xf, false);
   }
   template <int SLOT, int N> PW_FN static uint64_t wait_vm() {
     uint32_t lo, hi;

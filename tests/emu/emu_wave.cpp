@@ -121,7 +121,7 @@ struct EmuPS : EmuP {
   static uint64_t* slot(int s) { static uint64_t slots[2][Emu::N]; return &slots[s][Emu::self->cur]; }
   template <int SLOT> static void slot_zero() { *slot(SLOT) = 0; }
   template <int SLOT> static void fifo_load_async(const uint64_t* p, bool) { *slot(SLOT) = *p; }
-  static int32_t row1(int32_t old, int32_t v) { const int l = Emu::self->cur; return (l >= 16 && l < 32) ? v : old; }
+  template <int ROW> static int32_t rowmov(int32_t old, int32_t v) { const int l = Emu::self->cur; return (l >= 16 * ROW && l < 16 * ROW + 16) ? v : old; }
   template <int SLOT, int N> static uint64_t wait_vm() { return *slot(SLOT); }
   static uint32_t letters_dword(const uint8_t* m, int idx) {
     return (uint32_t)m[4 * idx] | ((uint32_t)m[4 * idx + 1] << 8) | ((uint32_t)m[4 * idx + 2] << 16) | ((uint32_t)m[4 * idx + 3] << 24);
