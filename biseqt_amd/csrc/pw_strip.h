@@ -143,7 +143,7 @@ struct StripFill {
   // the "nothing loaded" tag 0 -- so ONE comparison over all 64 lanes says whether the sub-chunk has arrived
   uint32_t wtag, wm255;       // lanes AH .. AH + 15: epoch << 8 and 255; else 0 and 0
   int32_t we0;                // lane - AH: this lane's column within a sub-chunk that sits in lanes AH .. AH + 15
-  int32_t ylim;               // 32 nkq - 64: the last column (real or virtual) a strip writes to its FIFO row
+  int32_t npolls, nspins;     // tuning aid (PWLIB_STRIP_TRACE): hand-overs that found their sub-chunk not there yet, polls they took
 
   PW_FN explicit StripFill(const StripParams& a_) : a(a_) {}
   PW_FN void stamp(int i) {
@@ -281,17 +281,18 @@ struct StripFill {
                                      hand-over (a taken branch costs a lone wavefront ~25 cycles; A/B: steady step 74.8 -> 73.6 ns, hops unchanged) */
 #endif
 #ifndef PW_STRIP_LEAD
-#define PW_STRIP_LEAD 8     /* FAST blocks: steps between the issue of a hand-over load and the hand-over: 8 | 12 | 16 */
+#define PW_STRIP_LEAD 8     /* FAST blocks: steps between the issue of a hand-over load and the hand-over: 4 | 8 | 12 | 16 */
 #endif
   // FAST blocks (steady ones and the first two of a strip below the first; run() admits them only when every column the
   // hand-overs of the block touch exists): the same hand-over without the range checks.
   //   load   columns c0 .. c0 + 15 into lanes AH .. AH + 15 of SLOT
-  //          (LIM, end blocks: columns behind `ylim` are never written -- the lanes that would hold them load nothing and
-  //           expect nothing; what they put into the feeders only ever reaches virtual cells)
+  //          (LIM, end blocks: only the columns up to Y are waited for -- the strip above writes its virtual columns as well,
+  //           but the last of them in its very last flush, and nothing real depends on them: the lanes that would hold them
+  //           load nothing and expect nothing; what they put into the feeders only ever reaches virtual cells)
   template <int SLOT, bool LIM>
   PW_FN void load_fast(int c0) const {
     P::template slot_zero<SLOT>();
-    const bool have = (unsigned)we0 < (unsigned)SUB && (!LIM || c0 + we0 <= ylim);
+    const bool have = (unsigned)we0 < (unsigned)SUB && (!LIM || c0 + we0 <= a.Y);
     if (have) P::template fifo_load_async<SLOT>(fin + (c0 + we0), PW_STRIP_ALWAYS_SC1 ? true : cross_in);
   }
   //   merge  the sub-chunk whose first column is c0 (sub-chunk S1) from SLOT into the feeders; VM = vector memory operations
@@ -301,7 +302,7 @@ struct StripFill {
   PW_FN void merge_fast(int c0, int S1) {
     uint64_t t = P::template wait_vm<SLOT, VM>();
     uint32_t want = ((uint32_t)(c0 + we0) & wm255) | wtag;
-    if (LIM) want = c0 + we0 <= ylim ? want : 0u;
+    if (LIM) want = c0 + we0 <= a.Y ? want : 0u;
     // (the one join of the two paths is in front of the unpacking, so the fast path runs straight through)
     if (__builtin_expect(!P::all((uint32_t)(t >> 32) == want), 0)) t = poll_sub<LIM>(t, S1);
     const int32_t pk = (int32_t)(uint32_t)t;
@@ -313,7 +314,7 @@ struct StripFill {
   template <bool LIM>
   PW_FN uint64_t poll_sub(uint64_t t, int S1) {
     const int e = SUB * S1 + we0;
-    const bool need = (unsigned)we0 < (unsigned)SUB && (!LIM || e <= ylim);
+    const bool need = (unsigned)we0 < (unsigned)SUB && (!LIM || e <= a.Y);
     const uint32_t want = tag_of(e);
     int spins = 0;
     while (!P::all(!need || (uint32_t)(t >> 32) == want)) {
@@ -321,6 +322,7 @@ struct StripFill {
       P::sleep();
       if (need) t = (cross_in || (spins & 3) == 0) ? P::fifo_poll(fin + e) : P::fifo_poll_local(fin + e);
     }
+    npolls++; nspins += spins;
     return need ? t : 0;
   }
   //   flush  lane 63's cells of steps k0 .. k0 + 15 (lanes 48 .. 63 of gP): columns k0 - 63 .. k0 - 48 (virtual ones behind
@@ -413,7 +415,7 @@ struct StripFill {
       // what was issued behind the load that this hand-over waits for: the mask store of block q - 1 in front of J = 1
       // (steady blocks: q >= 2, there always is one) and, when the load went out at the very start of the previous
       // sub-block (PW_STRIP_LEAD 16), the FIFO store of that sub-block
-      const bool mstore = (J & 1) && (MODE != 4 || q > 0);
+      const bool mstore = PW_STRIP_LEAD != 4 && (J & 1) && (MODE != 4 || q > 0);    // (lead 4: the load goes out behind it)
       const bool fstore = PW_STRIP_LEAD == 16 && MODE != 4;
       if (mstore && fstore) merge_fast<SLOT, 2, LIM>(SUB * SM, SM);
       else if (mstore || fstore) merge_fast<SLOT, 1, LIM>(SUB * SM, SM);
@@ -442,6 +444,7 @@ struct StripFill {
 #pragma unroll
       for (int g2 = 0; g2 < 2; g2++) {
         if (FAST && !NOIN && PW_STRIP_LEAD == 12 && h == 0 && g2 == 1) load_fast<1 - SLOT, LIM>(SUB * (SM + 1));
+        if (FAST && !NOIN && PW_STRIP_LEAD == 4 && h == 1 && g2 == 1) load_fast<1 - SLOT, LIM>(SUB * (SM + 1));
         const uint32_t l4 = letters_group(mwin[2 * hb + g2]);
         const uint32_t x4 = BROW ? P::perm_bytes(rowreg, l4) : l4;
         // the next block's letters: scalar loads share lgkmcnt with the lane exchange above, so they are issued right
@@ -511,7 +514,7 @@ struct StripFill {
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;
     gP = 0; cH = NEG; cU = NEG;
     we0 = lane - AH;
-    ylim = kStripBlock * a.nkq - 64;
+    npolls = 0; nspins = 0;
     wtag = (unsigned)we0 < (unsigned)SUB ? (a.epoch << 8) : 0u;
     wm255 = (unsigned)we0 < (unsigned)SUB ? 255u : 0u;
     vmatch = P::in_vgpr(a.match); vmis = P::in_vgpr(a.mismatch); vge = P::in_vgpr(a.ge); vgego = P::in_vgpr(a.ge + a.go);
@@ -545,9 +548,8 @@ struct StripFill {
     if (AH != 0) stamp(2);
     // steady: every lane holds an in-table cell on every step of the block and none its first or last one: blocks
     // 2 .. q_end - 1.  They get a loop of their own, so that nothing another kind of block needs is carried or updated in it.
-    // (The columns their hand-overs touch, up to k0 + 63, are all written by the strip above: k0 + 31 < Y <= ylim - ... see
-    // strip_fifo_pitch; the end blocks limit their hand-overs to `ylim`.)
-    // ... blocks q with k0 + 31 < Y whose hand-overs stay within the columns the strip above writes: k0 + 63 <= ylim
+    // Their hand-overs are not range-checked: every column they touch (up to k0 + 47) must be one the strip above writes --
+    // it writes the virtual columns up to 32 nkq - 64 too (strip_fifo_pitch) -- and writes before its last flush: q <= nkq - 4.
     const int q_last_cell = a.Y >= kStripBlock ? (a.Y - kStripBlock) / kStripBlock + 1 : 0;     // first q with k0 + 31 >= Y
     // (... and only in tables of more than 128 columns, where the strip above -- all of whose rows are in the table -- writes
     //  its virtual columns too; narrower tables run on the general code throughout)
@@ -580,11 +582,12 @@ struct StripFill {
       else block<2>(q);
     }
     // the last SUB steps' cells: a whole strip writes the virtual columns too (the end blocks of the strip below, whole as
-    // well, expect every column up to `ylim`), any other one the columns up to Y
+    // well, do not range-check), any other one the columns up to Y
     if (whole && PW_STRIP_FAST) flush_fast(kStripBlock * a.nkq - SUB);
     else flush_out(kStripBlock * a.nkq - SUB);
     store_masks();
     stamp(5);
+    if (a.stamps != nullptr && lane == 0) a.stamps[(uint64_t)w * 16 + 15] = ((uint64_t)(uint32_t)nspins << 32) | (uint32_t)npolls;
     finish();
   }
 

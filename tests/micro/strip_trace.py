@@ -68,5 +68,9 @@ print('shader clock per strip (counts / time, MHz): strip 0 %.0f, median %.0f, m
          ['%.0f' % mhz[i] for i in (len(ws) // 4, len(ws) // 2, -1)]))
 print('strip duration (granules seen -> end, us): strip 0 %.0f, strip %d %.0f, last %.0f; in shader cycles per step: %.1f, %.1f, %.1f'
       % (dur[0], len(dur) // 2, dur[len(dur) // 2], dur[-1], cyc[0] / (Y + 64), cyc[len(dur) // 2] / (Y + 64), cyc[-1] / (Y + 64)))
+polls = (t[:, 15] & 0xffffffff).astype(np.int64); spins = (t[:, 15] >> 32).astype(np.int64)
+print('hand-overs that had to poll, per strip (of %d): median %d, mean %.1f, max %d; polls per such hand-over: %.1f; strips %s: %s'
+      % ((Y + 64) // 16, np.median(polls), polls.mean(), polls.max(), spins.sum() / max(1, polls.sum()),
+         [0, 1, 100, len(t) // 2, len(t) - 1], [int(polls[i]) for i in (0, 1, 100, len(t) // 2, len(t) - 1)]))
 print('granules seen -> step 64: median %.2f us; step 64 -> 96: %.2f us; strip total: %.2f us'
       % (np.median(us[:, 3] - us[:, 2]), np.median(us[:, 4] - us[:, 3]), np.median(us[:, 5] - us[:, 2])))
