@@ -33,7 +33,7 @@ struct PlanModel {
 };
 
 static const PlanModel kPlanModel = {
-  /* strips (after the round-3 hand-over diet: tests/micro/few_pairs.py, profiles/round3_i_few_pairs.txt; config 3 itself comes out 10 % below) */ 0.045, 0.0092, 0.000062,
+  /* strips (after the round-3 hand-over diet: tests/micro/few_pairs.py, profiles/round3_i_few_pairs.txt; config 3 itself comes out 9 % below) */ 0.045, 0.0086, 0.00006,
   /* tiles  */ 0.05, 0.00043,
   /* wg_i32 */ {{2048, 0.45}, {4096, 0.7}, {8192, 1.3}, {0x7fffffff, 5.5}},
   /* wg_f64 */ {{1024, 0.47}, {2048, 0.6}, {4096, 1.0}, {8192, 2.7}, {0x7fffffff, 19.8}},
