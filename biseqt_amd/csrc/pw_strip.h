@@ -56,6 +56,8 @@ struct StripParams {
   uint32_t epoch;            // tag of this solve: granules of earlier solves never match (the buffer is never cleared)
   int32_t brule, endrule;
   int32_t match, mismatch, go, ge;
+  uint32_t rows[4];          // BROW kernels: row o of the substitution table, byte m = subst[o][m] (match / mismatch scoring, or
+                             // any matrix over at most 4 letters whose entries fit a signed byte: _alnchoice_M, _pw_internals.c:217-245)
   int32_t spin_limit;        // polls of one FIFO chunk before giving up
   double score_mul;          // reported score = the kernel's integer value times this (dyadic scaling, pw_types.h)
   // Placement (speed and store flavour only): strips are dealt in RUNS of run_len consecutive strips; run r is worked
@@ -85,8 +87,9 @@ PW_FN uint64_t strip_mask_index(int nkq, int w, int q, int lane) {      // in dw
   return ((uint64_t)((uint64_t)w * nkq + q) * 64 + lane) * 4;
 }
 
-// BROW (byte rows): alphabets of at most 4 letters and scores that fit a signed byte -- the lane holds its row of the
-// substitution table as 4 bytes (rowreg: byte m = score of the row's letter against mutant letter m), ONE v_perm_b32 turns
+// BROW (byte rows): alphabets of at most 4 letters and scores -- match / mismatch or a whole substitution matrix -- that fit
+// a signed byte: the lane holds its row of the substitution table as 4 bytes (rowreg: byte m = score of the row's letter
+// against mutant letter m), ONE v_perm_b32 turns
 // the 4 mutant letters of a group of 4 steps into their 4 scores, and a step adds its byte, sign-extended, to the diagonal
 // predecessor in one SDWA add -- instead of a byte compare, a select and an add per step.
 template <class P, bool TRACK, bool BROW = false>
@@ -505,10 +508,7 @@ struct StripFill {
     const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
     oc = (uint32_t)P::in_vgpr((int32_t)oseq[oi]);      // opaque: a compare known to be 8 bits wide is not folded into a byte select
     rowreg = 0;
-    if (BROW) {
-#pragma unroll
-      for (uint32_t m = 0; m < 4; m++) rowreg |= ((uint32_t)(oc == m ? a.match : a.mismatch) & 0xffu) << (8 * m);
-    }
+    if (BROW) rowreg = oc == 0 ? a.rows[0] : (oc == 1 ? a.rows[1] : (oc == 2 ? a.rows[2] : a.rows[3]));
     w0 = 0; w1 = 0; wpend = 0; wshift = 3u - ((uint32_t)lane & 3u); wfrom = (uint32_t)((lane - 4) & 63);
     kbest = 0; mprev_q = -1; bqv = NEG; ksnap = 0; kY = a.Y + lane;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;

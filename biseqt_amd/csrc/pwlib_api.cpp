@@ -394,7 +394,8 @@ int batch_plan(pw_batch* b) {
   // (a few standard-mode pairs: the strips, one pair after another, when they are estimated to finish before the 16-bit body
   //  on several wavefronts per pair would -- tests/micro/few_pairs.py: 2 kb x 2 kb, one pair 0.6 ms on the strips, 1.5 ms
   //  there; four pairs 2.3 ms and 1.6 ms)
-  const bool strips_win = latency_mode && b->simple && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
+  const bool strip_scores = b->simple || (integral && L <= 4 && smax <= 127 && smin >= -128 && !env_int("PWLIB_STRIP_NO_BYTE_ROWS", 0));
+  const bool strips_win = latency_mode && strip_scores && b->mode == pw::STD_MODE && min_x >= 127 && !(b->flags & PW_FLAG_DUMP_SCORES) &&
                           !env_int("PWLIB_NO_STRIP", 0) && !env_int("PWLIB_NO_SMALL_STRIP", 0) && !(b->flags & PW_FLAG_NO_STRIP) &&
                           (double)maxspan * maxabs < (double)(1 << 25) && est.strips_beat_packed_workgroups(model);
   if (prule >= 0 && pfits && !b->use_f64 &&
@@ -485,7 +486,7 @@ int batch_plan(pw_batch* b) {
     bool tiled = false;
     // (scores within +-2^25: the strip kernel tracks a row's best as 32 * H + step)
     const bool strip_ok = b->mode == pw::STD_MODE && !b->use_f64 && (double)maxspan * maxabs < (double)(1 << 25) &&
-                          b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 && b->simple &&
+                          b->variant != pw::VAR_GENERIC && b->variant != pw::VAR_FAST16 && strip_scores &&
                           !(b->flags & (PW_FLAG_DUMP_SCORES | PW_FLAG_FORCE_TILED | PW_FLAG_NO_STRIP)) && !env_int("PWLIB_NO_STRIP", 0);
     // ... always for tables wider than a workgroup holds; and for batches of a few pairs (at most 256: latency mode) when the
     // strips of all pairs, one pair after another, are estimated to finish before the slowest workgroup would (2 kb x 2 kb:
@@ -689,6 +690,13 @@ int xcc_queues(int device, int32_t* xcc_queue) {
   return cached_n[device];
 }
 
+// The strip kernel's byte rows (pw_strip.h, BROW): at most 4 letters, every score an integer that fits a signed byte
+bool strip_byte_rows_ok(const pw_batch* b) {
+  if (b->L > 4 || env_int("PWLIB_STRIP_NO_BYTE_ROWS", 0)) return false;
+  for (double v : b->subst) if (v != std::floor(v) || v < -128 || v > 127) return false;
+  return true;
+}
+
 // K2c: the strip pairs of a batch, one after another (each one fills the chip by itself)
 int launch_strip_fills(pw_batch* b, hipStream_t st) {
   static const int workers = std::max(1, env_int("PWLIB_STRIP_WAVES", 1024));
@@ -725,9 +733,12 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
       HIP_TRY(hipMemset(d_stamps, 0, (size_t)a.nstrips * 128));
       a.stamps = d_stamps;
     }
-    // byte rows (pw_strip.h, BROW): at most 4 letters, both scores a signed byte
-    const bool byte_rows = b->L <= 4 && a.match >= -128 && a.match <= 127 && a.mismatch >= -128 && a.mismatch <= 127 &&
-                           !env_int("PWLIB_STRIP_NO_BYTE_ROWS", 0);
+    const bool byte_rows = strip_byte_rows_ok(b);
+    if (!byte_rows && !b->simple) return fail("internal: a substitution matrix on the strips needs their byte rows");
+    if (byte_rows)
+      for (int o = 0; o < 4; o++)
+        for (int m = 0; m < 4; m++)
+          if (o < b->L && m < b->L) a.rows[o] |= ((uint32_t)(int32_t)b->subst[(size_t)o * b->L + m] & 0xffu) << (8 * m);
     HIP_TRY(pw::launch_strip_fill(a, track, byte_rows, workers, lds_kb << 10, st));
     if (d_stamps) {
       std::vector<uint64_t> h((size_t)a.nstrips * 16);

@@ -92,7 +92,7 @@ def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., misma
     return out
 
 
-def solve_strip(origin, mutant, alntype=0, match=1., mismatch=0., go=0., ge=0., epoch=7, byte_rows=True, **_):
+def solve_strip(origin, mutant, alntype=0, match=1., mismatch=0., go=0., ge=0., epoch=7, byte_rows=True, subst=None, **_):
     """Standard-mode problem through the strip pipeline (pw_strip.h): fill strip by strip, end-cell reduction, strip
     walker, fix-up.  Same result dict as :func:`solve`."""
     of = np.ascontiguousarray(np.asarray(origin, dtype=np.int32))
@@ -107,6 +107,11 @@ def solve_strip(origin, mutant, alntype=0, match=1., mismatch=0., go=0., ge=0., 
     txcap = X + Y + 2
     txbuf = C.create_string_buffer(txcap)
     lib().emu_set_strip_byte_rows(1 if byte_rows else 0)
+    if subst is not None:
+        S = np.ascontiguousarray(np.asarray(subst, dtype=np.float64))
+        lib().emu_set_strip_matrix(S.ctypes.data_as(C.POINTER(C.c_double)), int(S.shape[0]))
+    else:
+        lib().emu_set_strip_matrix(None, 0)
     rc = lib().emu_solve_strip(alntype, of.ctypes.data_as(C.POINTER(C.c_int)), X, mf.ctypes.data_as(C.POINTER(C.c_int)), Y,
                                C.c_double(match), C.c_double(mismatch), C.c_double(go), C.c_double(ge), C.c_uint(epoch),
                                info, C.byref(score), txbuf, txcap)

@@ -335,6 +335,13 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
 
 int g_strip_byte_rows = 1;
 extern "C" void emu_set_strip_byte_rows(int v) { g_strip_byte_rows = v; }
+// a substitution matrix for the next emu_solve_strip calls (L <= 4, integer entries within a signed byte; L = 0: match / mismatch)
+int g_strip_L = 0;
+double g_strip_subst[16];
+extern "C" void emu_set_strip_matrix(const double* S, int L) {
+  g_strip_L = (S != nullptr && L >= 1 && L <= 4) ? L : 0;
+  for (int i = 0; i < g_strip_L * g_strip_L; i++) g_strip_subst[i] = S[i];
+}
 
 // Standard-mode problem through the strip pipeline: strips in index order, end-cell reduction, strip walker, fix-up.
 extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mutant, int Y, double match, double mismatch,
@@ -372,6 +379,16 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
   bool brow = g_strip_byte_rows != 0 && a.match >= -128 && a.match <= 127 && a.mismatch >= -128 && a.mismatch <= 127;
   for (int i = 0; i < X; i++) brow = brow && origin[i] < 4;
   for (int i = 0; i < Y; i++) brow = brow && mutant[i] < 4;
+  if (g_strip_L > 0) {
+    if (!brow && g_strip_byte_rows == 0) return -8;         // a matrix needs the byte rows
+    brow = true;
+    for (int o = 0; o < g_strip_L; o++)
+      for (int m = 0; m < g_strip_L; m++)
+        a.rows[o] |= ((uint32_t)(int32_t)g_strip_subst[o * g_strip_L + m] & 0xffu) << (8 * m);
+  } else if (brow) {
+    for (int o = 0; o < 4; o++)
+      for (int m = 0; m < 4; m++) a.rows[o] |= ((uint32_t)(o == m ? a.match : a.mismatch) & 0xffu) << (8 * m);
+  }
   for (int w = 0; w < a.nstrips; w++) {
     Emu emu;
     bool ok = true;

@@ -19,7 +19,18 @@ from oracle import oracle as O                     # noqa: E402
 SCORES = [(1, -3, -5, -2), (1, 0, 0, 0), (2, -1, 0, -1), (5, -4, -10, -1), (1, -1, -1, -1), (1, -3, 0, -2), (1, 6, -5, -2)]
 
 
-def run(cases=60, seed=1, maxlen=700):
+def random_matrix(rng, L):
+    """A substitution matrix the strip kernel's byte rows take: integers within a signed byte (round 3)."""
+    hi = int(rng.choice([3, 9, 60, 127]))
+    S = rng.integers(-hi, hi + 1, size=(L, L))
+    if rng.random() < 0.7:
+        S[np.arange(L), np.arange(L)] = rng.integers(1, hi + 1, size=L)
+    if rng.random() < 0.3:
+        S = (S + S.T) // 2
+    return [[float(v) for v in row] for row in S]
+
+
+def run(cases=60, seed=1, maxlen=700, matrices=False):
     rng = np.random.default_rng(seed)
     nbad = npairs = 0
     t0 = time.time()
@@ -44,13 +55,20 @@ def run(cases=60, seed=1, maxlen=700):
             pairs.append((o, m))
         kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, match_score=sc[0], mismatch_score=sc[1], go_score=sc[2],
                   ge_score=sc[3], flags=W.PW_FLAG_FORCE_STRIP)
+        okw = dict(match=sc[0], mismatch=sc[1])
+        if matrices:
+            S = random_matrix(rng, 4)
+            kw = dict(alnmode=0, alntype=alntype, alphabet_len=4, subst_scores=S, go_score=min(sc[2], 0), ge_score=sc[3],
+                      flags=W.PW_FLAG_FORCE_STRIP)
+            okw = dict(subst=S)
+            sc = (None, None, min(sc[2], 0), sc[3])
         with BatchAligner(pairs, **kw) as b:
             assert 'k_fill_strip' in b.kernel_name, b.kernel_name
             for rep in range(2):                      # the second run re-uses the FIFO rows of the first
                 res = b.run()
                 txs = b.transcripts(res)
                 for k, (o, m) in enumerate(pairs):
-                    r = O.solve(o, m, L=4, mode=0, alntype=alntype, match=sc[0], mismatch=sc[1], go=sc[2], ge=sc[3])
+                    r = O.solve(o, m, L=4, mode=0, alntype=alntype, go=sc[2], ge=sc[3], **okw)
                     npairs += 1
                     why = None
                     if (int(res['opt_i'][k]), int(res['opt_j'][k])) != tuple(r['opt']):

@@ -252,6 +252,17 @@ def test_emu_strip_pipeline(oracle):
             assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
         n += 1
     assert n == 84
+    # a substitution matrix on the strips' byte rows (round 3)
+    for trial in range(16):
+        X = int(rng.integers(100, 500)); L = 4
+        o = rng.integers(0, L, X).astype(np.uint8)
+        m = synth.mutate(rng, o, 0.1, 0.05, 0.3) if trial % 2 else rng.integers(0, L, int(rng.integers(130, 400))).astype(np.uint8)
+        S = _random_matrix(rng, L, trial % 2)
+        kw = dict(L=L, mode=0, alntype=trial % 7, subst=[[float(v) for v in row] for row in S], go=float(-(trial % 3) * 3), ge=float(-1 - trial % 2))
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve_strip(o, m, epoch=100 + trial, **kw)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, X, len(m), kw)
     # table widths around the thresholds of the block kinds (pw_strip.h, run(): a strip's first two blocks take the fast
     # hand-over when Y > 128; steady blocks are those with k0 >= 64 and k0 + 63 <= Y; the rest run as ending / general ones)
     for trial, Y in enumerate((95, 126, 127, 128, 129, 130, 158, 159, 160, 190, 191, 192, 193, 222, 223, 224, 255, 256, 287)):

@@ -749,6 +749,9 @@ def test_strip_pipeline_forced_on_small_tables(oracle):
     spec.loader.exec_module(sc)
     assert sc.run(cases=120, seed=20261004, maxlen=900) == 0
     assert sc.run(cases=20, seed=20261005, maxlen=2600) == 0
+    # round 3: a substitution matrix over 4 letters whose entries fit a signed byte runs on the strips' byte rows too
+    # (_alnchoice_M reads subst_scores[o][m], _pw_internals.c:217-245; before, such pairs went to the tiled kernel)
+    assert sc.run(cases=70, seed=20261006, maxlen=900, matrices=True) == 0
 
 
 def test_config3_full_size_properties():
