@@ -651,6 +651,8 @@ PW_FN s2_t as_s2(uint32_t v) { return __builtin_bit_cast(s2_t, v); }
 PW_FN u2_t as_u2(uint32_t v) { return __builtin_bit_cast(u2_t, v); }
 PW_FN uint32_t add(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) + as_u2(b))); }
 PW_FN uint32_t sub(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (u2_t)(as_u2(a) - as_u2(b))); }
+// unsigned saturating subtract per half: max(a - b, 0) (v_pk_sub_u16 ... clamp)
+PW_FN uint32_t subsat(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(as_u2(a), as_u2(b))); }
 PW_FN uint32_t max(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(as_s2(a), as_s2(b))); }
 // NB min(x, 1) and (x >> 15) & c with LITERAL constants would be rewritten by the optimizer into compare +
 // select per half (the very pattern this kernel avoids), and inline asm gets padded with s_nop by the
@@ -674,6 +676,10 @@ PW_FN int32_t sl(uint32_t v) { return (int16_t)(v & 0xffffu); }
 PW_FN int32_t sh(uint32_t v) { return (int16_t)(v >> 16); }
 PW_FN uint32_t add(uint32_t a, uint32_t b) { return mk((a & 0xffffu) + (b & 0xffffu), (a >> 16) + (b >> 16)); }
 PW_FN uint32_t sub(uint32_t a, uint32_t b) { return mk((a & 0xffffu) - (b & 0xffffu), (a >> 16) - (b >> 16)); }
+PW_FN uint32_t subsat(uint32_t a, uint32_t b) {
+  const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
+  return mk(al > bl ? al - bl : 0u, ah > bh ? ah - bh : 0u);
+}
 PW_FN uint32_t max(uint32_t a, uint32_t b) { return mk((uint32_t)(sl(a) > sl(b) ? sl(a) : sl(b)), (uint32_t)(sh(a) > sh(b) ? sh(a) : sh(b))); }
 PW_FN uint32_t minu(uint32_t a, uint32_t b) {
   const uint32_t al = a & 0xffffu, bl = b & 0xffffu, ah = a >> 16, bh = b >> 16;
@@ -817,9 +823,15 @@ struct WaveFill16 {
                       uint32_t mc, uint32_t tv, uint32_t clampL = 0, uint32_t och = 0) {
     constexpr bool EDGE = EK != 0;
     uint32_t hM;
+    // (MAT, begin-anywhere rules outside the blocks where diagonals start: a started cell's score is never negative, so the
+    //  bias comes off with an unsigned SATURATING subtract -- the diagonal candidate is max(H + subst, 0) already and the
+    //  maximum with the begin candidate 0 below is not needed: one op less per cell pair.  Cells that have not started hold
+    //  the sentinel, a large unsigned value that the subtract leaves alone.)
+    constexpr bool FLOOR0 = MAT && ANYB && (EK & 1) == 0;
     if (MAT) {
       // oc / och: the matrix rows of the low / high cell's origin letter, mc: the two selectors
-      hM = pk::sub(pk::add(Hs, pk::perm(och, oc, mc)), BIASV);
+      const uint32_t hb = pk::add(Hs, pk::perm(och, oc, mc));
+      hM = FLOOR0 ? pk::subsat(hb, BIASV) : pk::sub(hb, BIASV);
     } else {
       const uint32_t ne = pk::minu(oc ^ mc, ONE);               // 0 where the letters match
       hM = pk::add(Hs, pk::mad(ne, NDELTA, MATCHV));
@@ -828,7 +840,7 @@ struct WaveFill16 {
     uint32_t nB;
     if (ANYB) {
       if (EK & 1) Hn = pk::max(Hn, pk::sign(pk::sub(tv, tf), SH15) & NEGV);   // B = 0 once started, sentinel before
-      else Hn = pk::max(Hn, 0u);                                 // B: an alignment may begin anywhere, score 0
+      else if (!FLOOR0) Hn = pk::max(Hn, 0u);                    // B: an alignment may begin anywhere, score 0
       nB = pk::minu(Hn, ONE);
     } else {
       // B = 0 in the one cell that may begin (step tf), the sentinel everywhere else

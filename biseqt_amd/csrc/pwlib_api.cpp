@@ -466,16 +466,17 @@ int batch_plan(pw_batch* b) {
     if (pbk) b->variant = pw::VAR_FAST16;
   }
   if (!b->simple && b->variant == pw::VAR_FAST16) b->packed_mat = 1;
-  // Match / mismatch scoring over at most 4 letters IS such a matrix, and the matrix form's cell pair is an op shorter (one
-  // v_perm_b32 instead of xor, min and multiply-add) at the price of registers (3 wavefronts per SIMD instead of 5).  Taken
-  // where an A/B on the GPU showed it faster (tests/micro/ab_simple_matrix.py, profiles/round3_h_ab_simple_matrix.txt):
-  // config 2's shape -- local rule, 8 diagonals per lane, one pair per wavefront: 3.50 -> 3.41 ms -- and standard-mode
-  // GLOBAL at 32 per lane (4.38 -> 4.27 ms); level at 16 per lane, slower lane-packed (+6 %) and under the overlap rule (+4 %).
-  // PWLIB_SIMPLE_AS_MATRIX=0 / 1: never / wherever the matrix form exists (A/B).
+  // Match / mismatch scoring over at most 4 letters IS such a matrix, and the matrix form's cell pair is shorter -- one
+  // v_perm_b32 instead of xor, min and multiply-add, and under the local rule the bias comes off with a saturating subtract
+  // that makes the maximum with the begin candidate 0 unnecessary -- at the price of registers (3 wavefronts per SIMD instead
+  // of 5).  Taken where an A/B on the GPU showed it faster (tests/micro/ab_simple_matrix.py,
+  // profiles/round3_h_ab_simple_matrix.txt): the local rule at 8 diagonals per lane, one pair per wavefront (config 2's shape:
+  // 3.50 -> 3.29 ms) and at 16 (2.23 -> 2.15 ms), standard-mode GLOBAL at 32 per lane (4.38 -> 4.27 ms); slower lane-packed
+  // (+4 %) and under the overlap rule (+4 %).  PWLIB_SIMPLE_AS_MATRIX=0 / 1: never / wherever the matrix form exists (A/B).
   if (b->simple && b->variant == pw::VAR_FAST16 && prule >= 0 && prule <= 2 && L >= 2 && L <= 4 && integral && smin <= 0 &&
       smax - smin <= 127 && !env_int("PWLIB_NO_PACKED_MAT", 0)) {
     const int knob = env_int("PWLIB_SIMPLE_AS_MATRIX", -1);
-    const bool measured = !pseg && b->packed_nw <= 1 && ((pbk == 8 && prule == 0) || (pbk == 32 && prule == 2));
+    const bool measured = !pseg && b->packed_nw <= 1 && (((pbk == 8 || pbk == 16) && prule == 0) || (pbk == 32 && prule == 2));
     if (knob > 0 || (knob < 0 && measured)) b->packed_mat = 1;
   }
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----

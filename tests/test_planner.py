@@ -29,9 +29,10 @@ def test_baseline_configs():
     finally:
         os.environ.pop('PWLIB_SIMPLE_AS_MATRIX')
     assert r['kernel'] == 'k_fill16<8, false> x4' and not r['matrix']
-    # ... not lane-packed, not under the overlap rule, not at 16 diagonals per lane (level there)
+    # ... not lane-packed, not under the overlap rule
     assert plan_only([(2000, 2010, -200, 200)] * 10000, alnmode=1, alntype=2, **CFG)['kernel'] == 'k_fill16<8, false, 1>'
-    assert plan_only([(2000, 2010, -400, 400)] * 3000, alnmode=1, alntype=1, **CFG)['kernel'] == 'k_fill16<16, false> x4'
+    assert plan_only([(300, 300, -10, 10)] * 20000, alnmode=1, alntype=1, **CFG)['kernel'] == 'k_fill16<4, true> x4'
+    assert plan_only([(2000, 2010, -400, 400)] * 3000, alnmode=1, alntype=1, **CFG)['kernel'] == 'k_fill16<16, false> x4 matrix'
     assert plan_only([(1000, 1000)] * 5000, alnmode=0, alntype=0, **CFG)['kernel'] == 'k_fill16<32, false, 2> matrix'
     # config 3: the strip pipeline
     r = plan_only([(100000, 100218)], alnmode=0, alntype=1, **CFG)
