@@ -1275,7 +1275,8 @@ PW_FN void trace_walk(const TraceParams& p, int pair, uint32_t* win /* WIN_WORDS
     // ---- refill: blocks cb .. cb - 3 of the current cell's diagonal group and of the neighbouring group on
     //      the side the cell sits on (paths drift by single diagonals); all loads issued back to back ----
     const int dd0 = x - y - dmin, t0 = x + y - s0;
-    if (x < 0 || y < 0 || dd0 < 0 || dd0 >= ndiag) { bad = 1; break; }   // never expected: see below
+    // (never expected -- see below; x > X or y > Y would index the mask plane behind its last block)
+    if (x < 0 || y < 0 || x > pdv.X || y > pdv.Y || dd0 < 0 || dd0 >= ndiag) { bad = 1; break; }
     const int cb = t0 >> 4;
     const int ga = dd0 >> lgG;
     int gb = ((dd0 & (G - 1)) >= (G >> 1)) ? ga + 1 : ga - 1;
@@ -1299,7 +1300,7 @@ PW_FN void trace_walk(const TraceParams& p, int pair, uint32_t* win /* WIN_WORDS
     while (true) {
       const int dd = x - y - dmin, t = x + y - s0;
       // a well-formed mask plane never leads outside the table; if it ever did (a kernel bug), stop
-      if (x < 0 || y < 0 || dd < 0 || dd >= ndiag) { bad = 1; done = true; break; }
+      if (x < 0 || y < 0 || x > pdv.X || y > pdv.Y || dd < 0 || dd >= ndiag) { bad = 1; done = true; break; }
       const int gg = dd >> lgG, b = t >> 4, kb = cb - b;
       if ((gg != ga && gg != gb) || kb < 0 || kb >= WIN_B) break;              // miss: refill
       const uint32_t w = win[(kb * 2 + (gg == ga ? 0 : 1)) * 4 + (dd & (G - 1))];

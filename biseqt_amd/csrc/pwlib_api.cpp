@@ -379,6 +379,18 @@ int batch_plan(pw_batch* b) {
   // (START_ANCHORED: begin at (0, 0) like GLOBAL, end at the first best cell, which must beat 0)
   else if (b->variant == pw::VAR_FAST_TRACK && b->brule == pw::BRULE_ORIGIN && b->endrule == pw::END_STD_LOCAL) prule = 5;
   if (!b->simple && (prule > 2 || !mat_ok)) prule = -1;   // (the packed matrix form: rules 0 .. 3, matrices it admits)
+  // The packed kernels keep cells that have not started (and cells beyond a diagonal's end) at a shallow 16-bit sentinel, pinned
+  // from below by a maximum; what keeps them from creeping UP is that letters outside a sequence "match nothing" and that
+  // scores nothing -- true only while the mismatch score (what the plain form gives such letters; with one letter the match
+  // score) is <= 0.  With mismatch > 0, which the API accepts, a diagonal that waits ~1400 steps for its first cell starts
+  // from a positive phantom score (found by the fuzz on a 3673-diagonal band, scores 1 / 6 / -5 / -2: a wrong end cell, and the
+  // walk from it left the mask plane).  Such scores take the matrix form where it applies (its off-table letters score the
+  // matrix MINIMUM, required <= 0) and the 32-bit kernels otherwise.
+  bool force_simple_mat = false;
+  if (b->simple && prule >= 0 && mm > 0) {
+    const bool can_mat = prule <= 2 && L >= 2 && L <= 4 && integral && smin <= 0 && smax - smin <= 127 && !env_int("PWLIB_NO_PACKED_MAT", 0);
+    if (can_mat) force_simple_mat = true; else prule = -1;
+  }
   if (prule >= 4 && env_int("PWLIB_NO_PACKED_ANCHORED", 0)) prule = -1;
   bool pfits = false;
   // (any substitution may be the best one: the API accepts mismatch > match)
@@ -477,7 +489,7 @@ int batch_plan(pw_batch* b) {
       smax - smin <= 127 && !env_int("PWLIB_NO_PACKED_MAT", 0)) {
     const int knob = env_int("PWLIB_SIMPLE_AS_MATRIX", -1);
     const bool measured = !pseg && b->packed_nw <= 1 && (((pbk == 8 || pbk == 16) && prule == 0) || (pbk == 32 && prule == 2));
-    if (knob > 0 || (knob < 0 && measured)) b->packed_mat = 1;
+    if (force_simple_mat || knob > 0 || (knob < 0 && measured)) b->packed_mat = 1;
   }
   // ---- pass 2: kernel geometry per pair, mask planes, launch classes ----
   for (int32_t k = 0; k < b->n; k++) {

@@ -325,3 +325,43 @@ def test_protein_style_integer_matrix_on_the_fast_kernels(oracle):
             assert (res == resg).all() and txs == txsg, (name, nameg)
         okw = dict(L=L, mode=mode, alntype=alntype, diag_range=dr, subst=[[float(v) for v in row] for row in subst], go=-10, ge=-1)
         _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, max(1, n // 20), name)
+
+
+def test_positive_mismatch_scores_and_long_waits(oracle):
+    """Regression (round 3, found by tests/micro/fuzz_gpu.py, seed 9551): the API accepts a mismatch score above 0.  The plain
+    form of the packed kernels scores letters outside a sequence as a mismatch, so a diagonal that waits long for its first
+    cell crept up from the 16-bit sentinel and started from a positive phantom score -- a wrong end cell, and the walk from it
+    left the mask plane (a GPU memory fault).  Such scores now take the packed matrix form where it applies (off-table letters
+    score the matrix minimum, <= 0) and the 32-bit kernels otherwise; and the walker refuses cells beyond (X, Y).  Cases: the
+    pair the fuzz saved (3673-diagonal band, 20 letters, 1 / 6 / -5 / -2), the same shape over 4 letters with -1 / 2 (matrix
+    form), and batches of ordinary shapes with both score sets."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'regress', 'mw_mismatch_9551.npz'))
+    o, m = d['o'], d['m']
+    band = tuple(int(v) for v in d['band'])
+    kw = dict(alnmode=1, alntype=1, alphabet_len=20, match_score=1, mismatch_score=6, go_score=-5, ge_score=-2)
+    okw = dict(L=20, mode=1, alntype=1, match=1, mismatch=6, go=-5, ge=-2, diag_range=band)
+    for n in (1, 3):
+        name, _, res, txs, rcs = _run([(o, m)] * n, diag_range=[band] * n, **kw)
+        assert 'k_fill16' not in name, name
+        _check_vs_oracle(oracle, [(o, m)] * n, res, txs, rcs, okw, 1, ('saved pair', n))
+    rng = np.random.default_rng(20261008)
+    o4 = rng.integers(0, 4, 524).astype(np.uint8)
+    m4 = rng.integers(0, 4, 3656).astype(np.uint8)
+    for sc, expect_matrix in (((-1, 2, -2, -1), True), ((1, 6, -5, -2), False), ((2, 3, -1, -1), False)):
+        kw4 = dict(alnmode=1, alntype=1, alphabet_len=4, match_score=sc[0], mismatch_score=sc[1], go_score=sc[2], ge_score=sc[3])
+        okw4 = dict(L=4, mode=1, alntype=1, match=sc[0], mismatch=sc[1], go=sc[2], ge=sc[3], diag_range=band)
+        name, _, res, txs, rcs = _run([(o4, m4)], diag_range=[band], **kw4)
+        assert ('k_fill16' in name) == expect_matrix and (not expect_matrix or 'matrix' in name), (sc, name)
+        _check_vs_oracle(oracle, [(o4, m4)], res, txs, rcs, okw4, 1, ('4 letters', sc))
+        for mode, alntype, dr in ((1, 1, (-300, 280)), (1, 2, (-150, 200)), (0, 1, None), (0, 0, None)):
+            pairs = _pairs(rng, 40, 150, 600)
+            kwb = dict(kw4, alnmode=mode, alntype=alntype)
+            okwb = dict(okw4, mode=mode, alntype=alntype)
+            okwb.pop('diag_range')
+            if dr is not None:
+                kwb['diag_range'] = dr
+                okwb['diag_range'] = dr
+            name, _, res, txs, rcs = _run(pairs, **kwb)
+            assert 'k_fill16' not in name or 'matrix' in name, (sc, mode, alntype, name)
+            _check_vs_oracle(oracle, pairs, res, txs, rcs, okwb, 1, (sc, mode, alntype))

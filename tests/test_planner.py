@@ -119,3 +119,25 @@ def test_planning_errors_are_reported():
         plan_only([(-1, 5)], alnmode=0, alntype=0)
     with pytest.raises(RuntimeError, match='type'):
         plan_only([(5, 5)], alnmode=0, alntype=9)
+
+
+def test_positive_mismatch_scores_never_take_the_plain_packed_form():
+    """The plain form of the packed kernels scores letters outside a sequence as a mismatch; with a mismatch score above 0 (the
+    API accepts it) cells that wait for their diagonal's first cell would creep up from the 16-bit sentinel.  The matrix form
+    (off-table letters score the matrix minimum, <= 0) takes such scores where it applies, the 32-bit kernels otherwise."""
+    shapes = {'config 2': ([(2000, 2010, -200, 200)] * 10000, dict(alnmode=1, alntype=1)),
+              'overlap': ([(2000, 2010, -200, 200)] * 10000, dict(alnmode=1, alntype=2)),
+              'lane-packed': ([(300, 300, -10, 10)] * 20000, dict(alnmode=1, alntype=1)),
+              'wide band': ([(524, 3656, -3414, 258)] * 3, dict(alnmode=1, alntype=1)),
+              'standard': ([(1000, 1000)] * 5000, dict(alnmode=0, alntype=0))}
+    for tag, (sh, kw) in shapes.items():
+        for L in (1, 4, 20):
+            for sc in ((1, 6, -5, -2), (2, 3, -1, -1), (1, 100, -5, -2)):
+                k = plan_only(sh, alphabet_len=L, match_score=sc[0], mismatch_score=sc[1], go_score=sc[2], ge_score=sc[3], **kw)['kernel']
+                assert 'k_fill16' not in k, (tag, L, sc, k)
+            k = plan_only(sh, alphabet_len=L, match_score=-1, mismatch_score=2, go_score=-2, ge_score=-1, **kw)['kernel']
+            # (with ONE letter the mismatch score never occurs and off-table letters score the match score, here -1)
+            assert 'k_fill16' not in k or (L == 4 and 'matrix' in k) or L == 1, (tag, L, k)
+            # ... and a mismatch score of 0 or below keeps the packed kernels
+            k = plan_only(sh, alphabet_len=max(L, 2), match_score=1, mismatch_score=0, go_score=-2, ge_score=-1, **kw)['kernel']
+            assert 'k_fill16' in k or 'strip' in k, (tag, L, k)
