@@ -732,6 +732,9 @@ PW_FN int32_t hi_s(uint32_t v) { return (int32_t)(int16_t)(v >> 16); }
 //   5  START_ANCHORED (standard) begin at (0, 0) only like rule 2 (negative scores, deep sentinel), end = the first best
 //                                 cell anywhere, which must beat 0 (_pw_internals.c:342): the running best is tracked as a
 //                                 key over max(H, 0), so real scores must stay within [-23000, 8000]
+// CONTRACT of the plain (match / mismatch) form: letters outside a sequence never match, i.e. cells that have not started and
+// cells beyond a diagonal's end take the MISMATCH score on their diagonal move -- which must be <= 0, or they creep up from
+// the sentinel (the host planner admits the plain form only then; the matrix form scores such letters with the matrix minimum).
 // MAT: the diagonal candidate takes its score from an integer substitution matrix of up to 4 x 4 letters instead of
 // match / mismatch (_alnchoice_M, _pw_internals.c:217-245: subst_scores[o][m]).  The origin window then carries, per
 // cell, the origin letter's ROW of the matrix -- four bytes subst[o][.] - min(subst) (times 4 under rule 3), at most 127

@@ -120,9 +120,7 @@ def run(budget, seed, long_mode=False, max_batches=None):
         subst = make_matrix(rng, L) if (not long_mode and rng.random() < 0.3) else None
         kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, go_score=sc[2], ge_score=sc[3], flags=flags, check_band=False)
         if subst is not None:
-            kw['subst_scores'] = subst
-            if flags & W.PW_FLAG_FORCE_STRIP:
-                kw['flags'] = flags = 0                        # (the strips serve match / mismatch scoring only)
+            kw['subst_scores'] = subst                         # (round 3: the strips take 4-letter byte-range matrices too; others fall through)
         else:
             kw.update(match_score=sc[0], mismatch_score=sc[1])
         if mode == 1:
