@@ -32,7 +32,7 @@ def lib():
 
 def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., mismatch=0., go=0., ge=0.,
           diag_range=None, origin_range=None, mutant_range=None, use_double=False, force_generic=False,
-          bk=8, want_table=False, packed16=False, **_):
+          bk=8, want_table=False, packed16=False, waves=1, **_):
     o = np.asarray(origin, dtype=np.int32)
     m = np.asarray(mutant, dtype=np.int32)
     if L is None:
@@ -60,6 +60,7 @@ def solve(origin, mutant, mode=0, alntype=0, subst=None, L=None, match=1., misma
         nd = X + Y + 1
         hd = np.zeros(nd * (min(X, Y) + 1), np.float64)
         hp = hd.ctypes.data_as(C.POINTER(C.c_double))
+    lib().emu_set_waves(int(waves))
     rc = lib().emu_solve(mode, alntype, of.ctypes.data_as(C.POINTER(C.c_int)), X,
                          mf.ctypes.data_as(C.POINTER(C.c_int)), Y, L,
                          S.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(go), C.c_double(ge),

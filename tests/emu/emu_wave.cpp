@@ -22,13 +22,15 @@
 namespace {
 
 struct Emu {
-  static const int N = 64;
-  ucontext_t main_ctx, ctx[N];
-  std::vector<char> stacks[N];
-  bool done[N];
+  static const int N = 64;          // lanes of a wavefront
+  static const int MAXN = 512;      // ... of a workgroup of up to 8 wavefronts (the multi-wavefront kernels: `n` = 64 x wavefronts)
+  int n = N;
+  ucontext_t main_ctx, ctx[MAXN];
+  std::vector<char> stacks[MAXN];
+  bool done[MAXN];
   int cur;
-  int xch[2][N];
-  unsigned phase[N];
+  int xch[2][MAXN];
+  unsigned phase[MAXN];
   std::function<void()> body;
   static Emu* self;
 
@@ -41,7 +43,7 @@ struct Emu {
   void run(std::function<void()> fn) {
     body = fn;
     self = this;
-    for (int l = 0; l < N; l++) {
+    for (int l = 0; l < n; l++) {
       stacks[l].resize(1 << 18);
       done[l] = false; phase[l] = 0;
       getcontext(&ctx[l]);
@@ -53,7 +55,7 @@ struct Emu {
     bool any = true;
     while (any) {
       any = false;
-      for (int l = 0; l < N; l++) {
+      for (int l = 0; l < n; l++) {
         if (done[l]) continue;
         cur = l;
         swapcontext(&main_ctx, &ctx[l]);
@@ -68,7 +70,7 @@ struct Emu {
     xch[ph][l] = v;
     barrier();
     cur = l;   // (the scheduler sets cur before resuming; keep the local view explicit)
-    return (src_lane >= 0 && src_lane < N) ? xch[ph][src_lane] : old;
+    return (src_lane >= 0 && src_lane < n) ? xch[ph][src_lane] : old;
   }
 };
 Emu* Emu::self = nullptr;
@@ -91,6 +93,25 @@ struct EmuP {
   static constexpr bool kVirtualLanes = false;
   static constexpr bool kBatchedShifts = false;
 };
+
+// A workgroup of several wavefronts as ONE long row of lanes (pw_device.h, DevPM: k_fill_mw / k_fill16_mw): the value that
+// crosses a wavefront boundary goes through LDS there; here every lane simply has a neighbour.
+struct EmuPM : EmuP {
+  static int nlanes() { return Emu::self->n; }
+  static int nwaves() { return Emu::self->n / 64; }
+  static constexpr bool kBatchedShifts = true;
+  template <int N> static void shrv(int32_t* v, const int32_t* old, int) {
+    Emu* e = Emu::self;
+    for (int i = 0; i < N; i++) v[i] = e->exchange(v[i], e->cur - 1, old[i]);
+  }
+  template <int N> static void shlv(int32_t* v, const int32_t* old, int) {
+    Emu* e = Emu::self;
+    for (int i = 0; i < N; i++) v[i] = e->exchange(v[i], e->cur + 1, old[i]);
+  }
+  static int32_t wave_bcast(int32_t v, int w) { Emu* e = Emu::self; return e->exchange(v, 64 * w, 0); }
+};
+int g_waves = 1;
+extern "C" void emu_set_waves(int w) { g_waves = w < 1 ? 1 : (w > 8 ? 8 : w); }
 
 // the strip pipeline (pw_strip.h): same lanes; the FIFO between strips is plain memory (strips run one after another)
 struct EmuPS : EmuP {
@@ -155,6 +176,15 @@ struct EmuPS : EmuP {
 template <typename T, int BK, bool BANY, bool TRACK, bool GENERIC>
 void run_fill(const pw::FillParams<T>& a, const pw::PairDesc& pd, const T* subst) {
   Emu emu;
+  if (g_waves > 1) {
+    emu.n = 64 * g_waves;
+    emu.run([&]() {
+      pw::WaveFill<EmuPM, T, BK, BANY, TRACK, GENERIC> w(a, pd, subst);
+      w.pair_slot = 0;
+      w.run();
+    });
+    return;
+  }
   emu.run([&]() {
     pw::WaveFill<EmuP, T, BK, BANY, TRACK, GENERIC> w(a, pd, subst);
     w.pair_slot = 0;
@@ -172,6 +202,13 @@ template <int BK> struct Run16<int32_t, BK> {
   template <bool SEG, int RULE, bool MAT>
   static void one(const pw::FillParams<int32_t>& a, const pw::WaveDesc& wd) {
     Emu emu;
+    if constexpr (!SEG) {
+      if (g_waves > 1) {
+        emu.n = 64 * g_waves;
+        emu.run([&]() { pw::WaveFill16<EmuPM, BK, false, RULE, MAT> w(a, wd); w.run(); });
+        return;
+      }
+    }
     emu.run([&]() { pw::WaveFill16<EmuP, BK, SEG, RULE, MAT> w(a, wd); w.run(); });
   }
   template <int RULE, bool MAT>
@@ -188,7 +225,7 @@ template <int BK> struct Run16<int32_t, BK> {
       // packed16 == 3: the scores-times-4 form of rule 0 (the caller keeps the scores below 2048); 4: the same, lane-packed
       const bool seg = g_packed_mode == 1 || g_packed_mode == 4;
       const bool x4 = g_packed_mode == 3 || g_packed_mode == 4;
-      wd.nl = seg ? pd.nl : 64;
+      wd.nl = seg ? pd.nl : 64 * g_waves;
       const bool local_end = a.endrule == pw::END_STD_LOCAL || a.endrule == pw::END_BANDED_LOCAL;
       int rule;
       if (a.brule == pw::BRULE_ANY) rule = local_end ? (x4 ? 3 : 0) : 4;                 // LOCAL / B_LOCAL; END_ANCHORED
@@ -236,7 +273,8 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   info[4] = -1; info[5] = -1; info[6] = 0; info[7] = 0; info[8] = 0; info[9] = 0;
   if (pl.rc != 0) return 0;
   if (pl.ndiag <= 0) return 0;
-  if ((int64_t)64 * bk < pl.ndiag) return -3;
+  if ((int64_t)64 * g_waves * bk < pl.ndiag) return -3;
+  if (g_waves > 1 && (packed16 == 1 || packed16 == 4)) return -6;          // (lane packing is a one-wavefront layout)
   // arena: origin at 0, mutant after it, both padded
   const int opad = ((X > 0 ? X : 1) + 31) / 16 * 16;
   const int mpad = ((Y > 0 ? Y : 1) + 31) / 16 * 16 + 16;
@@ -250,8 +288,8 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
   pd.nblocks = pl.nblocks; pd.steady_b0 = pl.steady_b0; pd.steady_b1 = pl.steady_b1;
   pd.h_pitch = (X < Y ? X : Y) + 1;
   pd.tx_cap = X + Y + 1; pd.bk = bk; pd.solvable = 1;
-  pd.nl = 64;
-  std::vector<uint32_t> masks((size_t)(pl.nblocks + 1) * 64 * bk + 64, 0xdeadbeefu);   // + spare row and slack like the product
+  pd.nl = 64 * g_waves;
+  std::vector<uint32_t> masks((size_t)(pl.nblocks + 1) * pd.nl * bk + 64, 0xdeadbeefu);   // + spare row and slack like the product
   std::vector<T> hd;
   if (hdump) hd.assign((size_t)pl.ndiag * pd.h_pitch, T(0));
   std::vector<T> sub((size_t)L * L);
@@ -298,7 +336,7 @@ int solve_T(int mode, int type, const int* origin, int X, const int* mutant, int
     a.mat_bias = scale * (int)(-smin);
   }
   if (packed16 && !generic && !use16) return -5;                   // the caller asked for a packed kernel that does not exist
-  if (use16) pd.nl = (pl.ndiag + bk - 1) / bk;
+  if (use16 && g_waves == 1) pd.nl = (pl.ndiag + bk - 1) / bk;
   switch (bk) {
     case 2: dispatch_variant<T, 2>(a, pd, sub.data(), generic, bany, track, use16); break;
     case 4: dispatch_variant<T, 4>(a, pd, sub.data(), generic, bany, track, use16); break;

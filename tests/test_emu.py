@@ -410,3 +410,63 @@ def test_emu_packed16_anchored_rules(oracle):
             assert a.get(key) == b.get(key), (trial, key, a.get(key), b.get(key), kw, bk, X, len(m))
         n += 1
     assert n > 140
+
+
+def test_emu_multi_wavefront_kernels(oracle):
+    """The multi-wavefront kernels (pw_device.h: k_fill16_mw, k_fill_mw -- a workgroup of 2 .. 8 wavefronts as one long row of
+    lanes, for bands wider than a wavefront holds and for the low-latency layout of a few pairs) had no CPU coverage until
+    round 3: the emulator now runs 64 x wavefronts fibers, the cross-wavefront hand-over being a neighbour exchange.  Packed
+    16-bit body (plain, scores times 4, matrix form, overlap / global / anchored rules), 32-bit and f64 bodies, on banded
+    and standard-mode problems whose diagonals do not fit one wavefront at the chosen lane width -- among them the shape of the
+    round's fuzz find (origin much shorter than mutant, band far below the main diagonal), with admissible scores."""
+    from biseqt_amd import synth
+    rng = np.random.default_rng(20261009)
+    n = 0
+    for trial in range(44):
+        kind = trial % 4
+        if kind == 0:                                           # related pair, wide band
+            X = int(rng.integers(150, 420)); o = rng.integers(0, 4, X).astype(np.uint8)
+            m = synth.mutate(rng, o, 0.08, 0.04, 0.3)
+            dr = (-int(rng.integers(100, len(m))), int(rng.integers(80, X)))
+        elif kind == 1:                                         # origin much shorter than mutant, band far below the main diagonal
+            X = int(rng.integers(40, 90)); o = rng.integers(0, 4, X).astype(np.uint8)
+            m = rng.integers(0, 4, int(rng.integers(500, 700))).astype(np.uint8)
+            k = int(rng.integers(200, 400)); m[k:k + X] = o
+            dr = (-len(m) + int(rng.integers(0, 60)), int(rng.integers(0, X)))
+        elif kind == 2:                                         # mutant much shorter
+            m = rng.integers(0, 4, int(rng.integers(40, 90))).astype(np.uint8)
+            o = rng.integers(0, 4, int(rng.integers(450, 650))).astype(np.uint8)
+            dr = (-int(rng.integers(0, len(m))), len(o) - int(rng.integers(0, 60)))
+        else:                                                   # standard mode: every diagonal
+            X = int(rng.integers(130, 300)); o = rng.integers(0, 4, X).astype(np.uint8)
+            m = synth.mutate(rng, o, 0.1, 0.05, 0.3)
+            dr = None
+        mode = 0 if dr is None else 1
+        alntype = [1, 0, 2, 3, 4, 5, 6][trial % 7] if mode == 0 else [1, 2, 0][trial % 3]
+        if mode == 1 and alntype == 0:                          # B_GLOBAL: the band must hold both corners
+            dr = (min(dr[0], len(o) - len(m), 0), max(dr[1], len(o) - len(m), 0))
+        ndiag = (len(o) + len(m) + 1) if dr is None else (min(dr[1], len(o)) - max(dr[0], -len(m)) + 1)
+        bk = 4 if ndiag <= 2048 else 8
+        waves = (ndiag + 64 * bk - 1) // (64 * bk)
+        if waves < 2:
+            bk, waves = 4, 2
+        body = trial % 5                                        # 0 / 1 packed, 2 packed matrix, 3 32-bit, 4 f64
+        kw = dict(L=4, mode=mode, alntype=alntype, go=float(-(trial % 3) * 2), ge=float(-1 - trial % 2))
+        if dr is not None:
+            kw['diag_range'] = dr
+        if body == 2:
+            kw['subst'] = _random_matrix(rng, 4, 1)
+        else:
+            sc = [(1, -3), (2, -1), (1, 0), (5, -4)][trial % 4]
+            kw.update(match=float(sc[0]), mismatch=float(sc[1]))
+        ek = dict(bk=bk, waves=waves)
+        if body <= 2:
+            ek['packed16'] = 3 if (body == 1 and mode == 1 and alntype == 1) or (body == 1 and mode == 0 and alntype == 1) else 2
+        elif body == 4:
+            ek['use_double'] = True
+        a = oracle.solve(o, m, **kw)
+        b = emu.solve(o, m, **kw, **ek)
+        for key in ('init_rc', 'opt', 'score', 'transcript', 'origin_idx', 'mutant_idx', 'tb_null', 'would_panick'):
+            assert a.get(key) == b.get(key), (trial, key, len(o), len(m), kw, ek)
+        n += 1
+    assert n == 44
