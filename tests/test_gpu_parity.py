@@ -366,20 +366,24 @@ def test_config2_ten_thousand_pairs_every_kernel_agrees(oracle):
 
 def test_packed16_admission_with_mismatch_above_match(oracle):
     """A mismatch score above the match score bounds the running score by min(X, Y) * mismatch: a 7000 x 7000 local
-    band (36 221 at the optimum) must not take the 16-bit kernel, and a 1000 x 1000 one (bounded by 6000) may and
-    must still equal the 32-bit kernel and the oracle."""
+    band (about 35 000 at the optimum) must not take the 16-bit kernel, and a 1000 x 1000 one (bounded by 7000) may and
+    must still equal the 32-bit kernel and the oracle.  (Round 3: a mismatch score above 0 reaches the packed kernels
+    through their matrix form only -- which needs a score <= 0 in the matrix, here the match score; the plain form would let
+    cells outside the table creep up from the sentinel: DESIGN.md section 5.  With 1 / 6 the 32-bit kernels run.)"""
     from biseqt_amd import _pwlib as W
     from biseqt_amd import synth
     from biseqt_amd.batch import BatchAligner
     rng = synth.rng_for(242)
-    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-10, 10), match_score=1, mismatch_score=6,
+    kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-10, 10), match_score=-1, mismatch_score=7,
               go_score=-5, ge_score=-2)
     for n, packed in ((7000, False), (1000, True)):
         o = synth.rand_seqs(rng, 1, n)[0]
         m = synth.rand_seqs(rng, 1, n)[0]
         pairs = [(o, m)] * 300                              # enough pairs to leave latency mode
+        with BatchAligner(pairs, **dict(kw, match_score=1, mismatch_score=6)) as b:
+            assert 'k_fill16' not in b.kernel_name, b.kernel_name
         with BatchAligner(pairs, **kw) as b:
-            assert ('k_fill16' in b.kernel_name) == packed, b.kernel_name
+            assert ('k_fill16' in b.kernel_name) == packed and (not packed or 'matrix' in b.kernel_name), b.kernel_name
             res = b.run()
             txs = b.transcripts(res)
         with BatchAligner(pairs, flags=W.PW_FLAG_NO_PACKED16, **kw) as b:
@@ -387,7 +391,7 @@ def test_packed16_admission_with_mismatch_above_match(oracle):
             res2 = b.run()
             txs2 = b.transcripts(res2)
         assert (res == res2).all() and txs == txs2
-        r = oracle.solve(o, m, L=4, mode=1, alntype=1, diag_range=(-10, 10), match=1, mismatch=6, go=-5, ge=-2)
+        r = oracle.solve(o, m, L=4, mode=1, alntype=1, diag_range=(-10, 10), match=-1, mismatch=7, go=-5, ge=-2)
         assert (res['opt_i'][0], res['opt_j'][0]) == r['opt'] and res['score'][0] == r['score']
         assert txs[0] == r['transcript']
         if not packed:
@@ -403,7 +407,7 @@ def test_scaled_packed_kernel_at_its_admission_bound(oracle):
     from biseqt_amd.batch import BatchAligner
     rng = synth.rng_for(77)
     for n, match, mismatch, scaled in ((409, 5, -4, True), (2047, 1, -3, True), (2047, 1, 0, True), (410, 5, -4, False),
-                                       (341, 2, 6, True), (342, 2, 6, False)):
+                                       (341, -2, 6, True), (342, -2, 6, False)):     # (mismatch above 0: the matrix form)
         o = synth.rand_seqs(rng, 1, n)[0]
         m2 = synth.mutate(rng, o, 0.05, 0.02, 0.3)
         kw = dict(alnmode=1, alntype=1, alphabet_len=4, diag_range=(-200, 200), match_score=match, mismatch_score=mismatch,

@@ -266,8 +266,12 @@ def test_anchored_types_on_their_packed_kernels(oracle, alntype, tag):
         name, dtype, res, txs, rcs = _run(pairs, **kw)
         name32, _, res32, txs32, _ = _run(pairs, flags=W.PW_FLAG_NO_PACKED16, **kw)
         assert 'k_fill16' not in name32, name32
-        if n > 256:
+        if n > 256 and mismatch <= 0:
             assert 'k_fill16' in name and tag in name, (name, n)
+        elif n > 256:
+            # a mismatch score above 0 does not reach the plain packed form (off-table letters score it: DESIGN.md section 5),
+            # and the anchored rules have no matrix form
+            assert 'k_fill16' not in name, (name, n)
         assert (res == res32).all() and txs == txs32, (name, kw)
         okw = dict(L=4, mode=0, alntype=alntype, match=match, mismatch=mismatch, go=go, ge=ge)
         _check_vs_oracle(oracle, pairs, res, txs, rcs, okw, max(1, n // 40), (name, kw))
