@@ -5,7 +5,8 @@ chosen to hit the places kernels break: alignments lying exactly on / next to a 
 not multiples of the lane width, identical sequences, shifted copies, low-complexity repeats (many ties), empty
 and one-letter sequences, clamped and infeasible bands, long pairs.
 
-    python tests/micro/fuzz_gpu.py [seconds] [seed] [long]      # long: banded pairs up to 14 kb, default kernels
+    python tests/micro/fuzz_gpu.py [seconds] [seed] [long | wide]      # long: banded pairs up to 14 kb, default kernels; wide: few pairs,
+                                                                       # bands thousands of diagonals wide, all score sets and flags
 """
 import os
 import sys
@@ -49,9 +50,11 @@ FLAGS = [0, 0, 0, W.PW_FLAG_NO_PACKED16, W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_GE
          W.PW_FLAG_FORCE_TILED | W.PW_FLAG_FORCE_F64, W.PW_FLAG_FORCE_STRIP, W.PW_FLAG_FORCE_STRIP]
 
 
-def make_pair(rng, L, maxlen):
+def make_pair(rng, L, maxlen, wide=False):
     kind = rng.integers(0, 8)
     n = int(np.exp(rng.uniform(0, np.log(maxlen)))) if rng.random() < 0.9 else int(rng.integers(0, 3))
+    if wide and rng.random() < 0.7:
+        n = int(rng.integers(maxlen // 4, maxlen + 1))          # (the wide mode wants long sequences, not a log-uniform length)
     if kind == 0:                                   # unrelated
         o = rng.integers(0, L, n); m = rng.integers(0, L, max(0, n + int(rng.integers(-n // 2 - 1, n // 2 + 2))))
     elif kind == 1:                                 # identical
@@ -107,17 +110,24 @@ def run(budget, seed, long_mode=False, max_batches=None):
         L = [2, 4, 4, 20][int(rng.integers(0, 4))]
         maxlen = [40, 300, 1500, 4000][int(rng.integers(0, 4))] if mode == 1 else [40, 300, 1200][int(rng.integers(0, 3))]
         n = int(rng.integers(1, 25))
-        if long_mode:
+        if long_mode == 'wide':
+            # few pairs, bands thousands of diagonals wide and far off the main diagonal, every score set: the multi-wavefront
+            # kernels, strips and tiles on tables whose diagonals start and end at very different steps (round 3: the regime
+            # of the fuzz's one late find)
+            maxlen, n = [1500, 4000, 9000][int(rng.integers(0, 3))], int(rng.integers(1, 5))
+            if mode == 0:
+                maxlen = min(maxlen, 2500)
+        elif long_mode:
             mode, maxlen, n = 1, 14000, int(rng.integers(1, 7))
             alntype = 1 if rng.random() < 0.7 else alntype % 3
             flags = 0 if rng.random() < 0.8 else flags
             sc = SCORES[int(rng.integers(0, 5))] if rng.random() < 0.8 else sc
         pairs, bands = [], []
         for _ in range(n):
-            o, m = make_pair(rng, L, maxlen)
+            o, m = make_pair(rng, L, maxlen, long_mode == 'wide')
             pairs.append((o, m))
             bands.append(make_band(rng, len(o), len(m), o, m))
-        subst = make_matrix(rng, L) if (not long_mode and rng.random() < 0.3) else None
+        subst = make_matrix(rng, L) if ((not long_mode or long_mode == 'wide') and rng.random() < 0.3) else None
         kw = dict(alnmode=mode, alntype=alntype, alphabet_len=L, go_score=sc[2], ge_score=sc[3], flags=flags, check_band=False)
         if subst is not None:
             kw['subst_scores'] = subst                         # (round 3: the strips take 4-letter byte-range matrices too; others fall through)
@@ -187,7 +197,8 @@ def run(budget, seed, long_mode=False, max_batches=None):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
-    nb, npairs, nbad = run(budget, seed, len(sys.argv) > 3 and sys.argv[3] == 'long')
+    mode = sys.argv[3] if len(sys.argv) > 3 else ''
+    nb, npairs, nbad = run(budget, seed, 'wide' if mode == 'wide' else mode == 'long')
     sys.exit(1 if nbad else 0)
 
 
