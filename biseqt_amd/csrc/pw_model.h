@@ -1,3 +1,4 @@
+#include <cmath>
 // pw_model.h -- the planner's timing model: every constant the kernel choice depends on, in ONE table, and the estimates
 // built from it.  Pure C++ (no HIP): used by pwlib_api.cpp (batch_plan) and readable by the tests.
 //
@@ -30,6 +31,13 @@ struct PlanModel {
   StepCost wg_f64[5];      // f64 body (the wide lanes spill kilobytes of registers: 8 kb x 8 kb takes 317 ms)
   StepCost wg_p16[3];      // packed 16-bit body (k_fill16_mw)
   double margin;           // one-after-another wins when its estimate < margin x the workgroups' estimate
+  // The packed kernels' lane layouts: cost of one slot-step relative to the lane-packed form at 8 diagonals per lane, by
+  // diagonals per lane 4, 8, .. 32 (pw_launch.h, kPackedBK), and what one pair per wavefront saves (its descriptor sits in
+  // scalar registers).  Fitted to tests/micro/overlap_all_bench.py (bands of 9 .. 111 diagonals under the overlap rule, 20 000 and
+  // 50 000 pairs per batch, PWLIB_PACKED_BK = 4s .. 32s) and tests/micro/ab_lane_packing.py (config 2's shape, local rule); both
+  // agree within 3 % (profiles/round3_n_lane_width.txt, round3_m_lane_packing.txt).
+  double seg_slot_cost[8];
+  double one_pair_discount;
 };
 
 static const PlanModel kPlanModel = {
@@ -39,7 +47,17 @@ static const PlanModel kPlanModel = {
   /* wg_f64 */ {{1024, 0.47}, {2048, 0.6}, {4096, 1.0}, {8192, 2.7}, {0x7fffffff, 19.8}},
   /* wg_p16 */ {{4096, 0.38}, {8192, 0.6}, {0x7fffffff, 1.2}},
   /* margin */ 0.9,
+  /* seg_slot_cost, 4 .. 32 diagonals per lane */ {1.08, 1.0, 0.98, 1.04, 1.1, 1.1, 1.06, 1.06},
+  /* one_pair_discount */ 0.93,
 };
+
+// n wavefronts on 1024 SIMDs: the last round is only partly filled.  With one or two rounds that costs in full (1250 wavefronts
+// take as long as 2048 would); with many rounds wavefronts of different lengths even most of it out.
+inline double last_round_factor(double nwaves) {
+  const double r = nwaves < 1024.0 ? 1.0 : nwaves / 1024.0;
+  const double c = std::ceil(r) / r;
+  return r < 3.0 ? c : 1.0 + 0.3 * (c - 1.0);
+}
 
 template <int N> inline double step_us(const StepCost (&t)[N], int ndiag) {
   for (int i = 0; i < N; i++) if (ndiag <= t[i].max_ndiag) return t[i].us;

@@ -428,27 +428,35 @@ int batch_plan(pw_batch* b) {
   else if (prule >= 0 && pfits && !b->use_f64 &&
       !(b->flags & (PW_FLAG_NO_PACKED16 | PW_FLAG_FORCE_TILED | PW_FLAG_FORCE_STRIP)) && maxnd <= 2048 &&
       nsolv > 0 && maxabs <= 100 && maxspan < 32000 && b->ge <= 0) {
-    // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar
-    // registers (measured ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the
-    // 64 x BK diagonal slots busy.  Packing is chosen when it buys at least 25 % more busy slots.
+    // Diagonals per lane and pairs per wavefront.  One pair per wave keeps the pair descriptor in scalar registers (measured
+    // ~7 % cheaper per cell); several pairs per wave (lane packing) keep more of the 64 x BK diagonal slots busy.  Each layout is
+    // priced (pw_model.h): what a slot-step costs at that lane width (the wide lanes pay for their registers) / the share of
+    // busy slots x a factor for the last, partly filled round of wavefronts over the SIMDs.  Round 3 found config 4's overlap
+    // batches -- bands of 9 .. 111 diagonals, 20 000 pairs -- on 28 diagonals per lane (69 % of the slots busy, but 1250
+    // wavefronts on 1024 SIMDs: 7.4 ms) where 8 per lane take 4.9 ms; with 50 000 pairs per batch 16 per lane win
+    // (profiles/round3_n_lane_width.txt).  Packing is taken when it is priced 5 % below one pair per wavefront.
     const char* forced = getenv("PWLIB_PACKED_BK");        // tuning / A-B: "<bk>" or "<bk>s" (force packing)
     if (forced && !*forced) forced = nullptr;
     const double meannd = (double)sumnd / nsolv;
-    double util1 = -1, utilp = -1; int bk1 = 0, bkp = 0, nlp = 0;
+    double cost1 = 1e300, costp = 1e300; int bk1 = 0, bkp = 0, nlp = 0;
     for (int i = 0; i < pw::kNumPackedBK; i++) {
       const int bk = pw::kPackedBK[i];
       if (forced && atoi(forced) != bk) continue;
       const int nl = (maxnd + bk - 1) / bk;
       if (nl > 64) continue;
-      const double u1 = meannd / (64.0 * bk);
-      if (u1 > util1 + 1e-9) { util1 = u1; bk1 = bk; }                       // smallest BK that fits
-      const double up = (double)(64 / nl) * meannd / (64.0 * bk);
+      if (!bk1) {                                                             // smallest BK that fits: one pair per wavefront
+        bk1 = bk;
+        cost1 = model.one_pair_discount * model.seg_slot_cost[i] * pw::last_round_factor((double)nsolv) / (meannd / (64.0 * bk));
+      }
+      const int ppw = 64 / nl;
+      const int64_t nwv = ((int64_t)nsolv + ppw - 1) / ppw;
       // (packing must leave at least one wavefront per SIMD: 20 000 pairs with a 21-diagonal band packed 64 to a wavefront are
       //  313 wavefronts with 12 cells per lane and step -- 0.69 ms against 0.41 ms for 10 to a wavefront)
-      const bool enough = forced || (int64_t)(nsolv + 64 / nl - 1) / (64 / nl) >= 1024;
-      if (64 / nl >= 2 && enough && up >= utilp - 1e-9) { utilp = up; bkp = bk; nlp = nl; }   // ties: the larger BK
+      const bool enough = forced || nwv >= 1024;
+      const double cp = model.seg_slot_cost[i] * pw::last_round_factor((double)nwv) / ((double)ppw * meannd / (64.0 * bk));
+      if (ppw >= 2 && enough && cp < costp - 1e-9) { costp = cp; bkp = bk; nlp = nl; }      // ties: the narrower lanes
     }
-    const bool want_seg = bkp && (!bk1 || utilp >= 1.25 * util1 || (forced && strchr(forced, 's')));
+    const bool want_seg = bkp && (!bk1 || costp < 0.95 * cost1 || (forced && strchr(forced, 's')));
     // pairs that fit one wavefront side by side at the narrowest lanes
     const int ppw1 = bk1 ? std::max(1, 64 / ((maxnd + bk1 - 1) / bk1)) : 1;
     if ((latency_mode || nsolv < 1024 * ppw1) && bk1 && !forced) {

@@ -58,6 +58,10 @@ def main():
     hi = np.minimum(recs['d_best'][sel].astype(np.int64) + recs['r_best'][sel], lens[pidx[:, 0]].astype(np.int64))
     dr = np.stack([lo, hi], axis=1)
     cells = (hi - lo + 1) * np.minimum(lens[pidx[:, 0]], lens[pidx[:, 1]]).astype(np.int64)
+    if len(sel):
+        nd = hi - lo + 1
+        print('  bands of the pairs to align: %d .. %d diagonals, mean %.1f, median %d, 90 %% below %d' %
+              (nd.min(), nd.max(), nd.mean(), np.median(nd), np.percentile(nd, 90)))
     t5 = time.perf_counter()
     dev_ms, tot_cells, nb, score_sum, kname = 0.0, 0, 0, 0.0, ''
     from biseqt_amd.overlap import aligned_batches
