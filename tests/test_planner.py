@@ -141,3 +141,22 @@ def test_positive_mismatch_scores_never_take_the_plain_packed_form():
             # ... and a mismatch score of 0 or below keeps the packed kernels
             k = plan_only(sh, alphabet_len=max(L, 2), match_score=1, mismatch_score=0, go_score=-2, ge_score=-1, **kw)['kernel']
             assert 'k_fill16' in k or 'strip' in k, (tag, L, k)
+
+
+def test_lane_layout_is_priced_not_just_packed():
+    """Many pairs with narrow bands of MIXED widths (config 4's alignment stage: 9 .. 111 diagonals, mean 77): the layout that
+    keeps most slots busy (28 diagonals per lane, 16 pairs per wavefront) leaves 1250 wavefronts for 1024 SIMDs at 20 000 pairs
+    and measured 7.4 ms against 4.9 ms at 8 per lane; with 50 000 pairs 16 per lane win (profiles/round3_n_lane_width.txt,
+    round3_o_layout_race.txt).  pw_model.h prices slot cost, busy share and the last round of wavefronts."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    kw = dict(alnmode=1, alntype=2, alphabet_len=4, **CFG)
+
+    def shapes(n):
+        r = rng.integers(4, 56, n)
+        r[0] = 55
+        return [(5000, 5000, -int(v), int(v)) for v in r]
+    assert plan_only(shapes(20000), **kw)['kernel'] == 'k_fill16<8, true, 1>'
+    assert plan_only(shapes(50000), **kw)['kernel'] == 'k_fill16<16, true, 1>'
+    # one band width, 81 diagonals: the narrowest lanes (three pairs per wavefront)
+    assert plan_only([(300, 300, -40, 40)] * 20000, alnmode=1, alntype=1, alphabet_len=4, **CFG)['kernel'] == 'k_fill16<4, true> x4'
