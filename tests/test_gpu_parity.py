@@ -819,6 +819,10 @@ def test_adversarial_fuzz_vs_oracle(oracle):
     assert nbad == 0 and npairs > 1000
     nb, npairs, nbad = fz.run(60, 20261005, long_mode=True, max_batches=25)
     assert nbad == 0
+    # (round 3) few pairs, bands thousands of diagonals wide and far off the main diagonal: tiles, strips, multi-wavefront
+    # kernels on tables whose diagonals start and end at very different steps -- the regime of the round's late find
+    nb, npairs, nbad = fz.run(40, 20261006, long_mode='wide', max_batches=120)
+    assert nbad == 0 and npairs > 100
 
 
 @pytest.mark.parametrize('latency_mode', ['0', '1'])
