@@ -44,6 +44,14 @@ FILL16_WAVES = {      # (bk, rule, matrix)
 for _e in filter(None, os.environ.get('PW_FILL16_WAVES_OVERRIDE', '').split(';')):
     _k, _v = _e.split('=')
     FILL16_WAVES[tuple(int(x) for x in _k.split(','))] = tuple(int(x) for x in _v.split(','))
+# A/B builds: PW_FILL16_UNR_OVERRIDE="8,3,1=2" sets the unroll depth of one instantiation (default: pw_wave.h, UNR).  Measured
+# for config 2's kernel (8, 3, 1): fully unrolled (4) at 3 wavefronts per SIMD, 166 VGPRs: fill 3.40 ms; 2 at 4 per SIMD (104
+# VGPRs) 3.54-3.60; 1 at 5 per SIMD (94 VGPRs) 3.67-3.70; 2 at 3 per SIMD 3.61 -- the instructions the full unrolling saves
+# (the letter-window shifts become register renames) are worth more than the wavefronts it costs.
+FILL16_UNR = {}
+for _e in filter(None, os.environ.get('PW_FILL16_UNR_OVERRIDE', '').split(';')):
+    _k, _v = _e.split('=')
+    FILL16_UNR[tuple(int(x) for x in _k.split(','))] = int(_v)
 TYPES = (('i32', 'int32_t'), ('f64', 'double'))
 # The f64 kernels never see a NaN (scores are validated finite, sums stay far from overflow): telling the compiler so lets
 # v_max_f64 take values that crossed lanes as bit patterns without a canonicalising v_max_f64 x, x in front.  It licenses no
@@ -81,7 +89,8 @@ def _jobs():
         # schedule leaves ~15% of the issue slots of the packed kernel to s_nop, this one none (measured)
         occ, occ_seg = FILL16_WAVES.get((bk, rule, mat), (0, 0)) if os.environ.get('PW_FILL16_OCCUPANCY', '1') != '0' else (0, 0)
         cmd = [HIPCC] + COMMON + ['-mllvm', '-amdgpu-sched-strategy=max-ilp', '-DPW_BK=%d' % bk, '-DPW_RULE=%d' % rule, '-DPW_MAT=%d' % mat,
-                                  '-DPW_FILL16_WAVES=%d' % occ, '-DPW_FILL16_WAVES_SEG=%d' % occ_seg, '-c',
+                                  '-DPW_FILL16_WAVES=%d' % occ, '-DPW_FILL16_WAVES_SEG=%d' % occ_seg] + \
+              (['-DPW_FILL16_UNR=%d' % FILL16_UNR[(bk, rule, mat)]] if (bk, rule, mat) in FILL16_UNR else []) + ['-c',
                os.path.join(HERE, 'pw_fill16_tu.hip'), '-o', obj]
         jobs.append((obj, cmd, [os.path.join(HERE, 'pw_fill16_tu.hip')]))
     obj = os.path.join(OBJ_DIR, 'pw_trace.o')

@@ -756,7 +756,11 @@ struct WaveFill16 {
   static_assert(BK % 4 == 0, "packed layout needs an even number of cells per step");
   static constexpr int R = BK / 2;      // cells per lane and step
   static constexpr int RH = R / 2;      // packed registers per parity
+#ifdef PW_FILL16_UNR
+  static constexpr int UNR = PW_FILL16_UNR;                      // (A/B builds: build.py, PW_FILL16_UNR_OVERRIDE)
+#else
   static constexpr int UNR = BK <= 8 ? 4 : (BK <= 16 ? 2 : 1);   // iterations unrolled per loop trip
+#endif
   static constexpr int32_t NEG16 = ANYB ? -8192 : -24000;
   static constexpr uint32_t SENT_O = 0xfffeu, SENT_M = 0xffffu;   // letters outside a sequence: match nothing
   // MAT: selector codes of a mutant letter in the low / high half of a register; outside the sequence 8 / 12, which both
