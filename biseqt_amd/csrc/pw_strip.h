@@ -661,13 +661,17 @@ PW_FN void strip_reduce(const StripParams& a) {
 // ---- traceback over the strip layout: one wavefront per pair ------------------------------------------------------
 // A walk is a chain of dependent steps, but in an alignment of similar sequences nine steps out of ten continue a
 // run of diagonal moves, and a run can be taken in ONE step: the wave keeps a window of the mask plane on chip (LDS:
-// all 64 rows of the current strip x 128 steps = 4 KB), lane j looks at the cell j moves up the diagonal from the
+// all 64 rows of kWalkStrips strips x 160 steps each = 20 KB), lane j looks at the cell j moves up the diagonal from the
 // current one, a ballot finds how many of them in a row are "pure M" (none of B, D, I kept: the first kept op is M
 // whatever led here), and the whole run is written with one store instruction.  Only the cells that break a run go
-// through the scalar predecessor rule (pw_wave.h, trace_walk).  The next window (further down this strip, or the strip
-// above, whichever the diagonal reaches first) is loaded while the current one is being walked.
-constexpr int kWalkGroups = 4;                        // 32-step groups per window
-constexpr int kWalkWinWords = kWalkGroups * 64 * 4;   // dwords of LDS
+// through the scalar predecessor rule (pw_wave.h, trace_walk).  The next window (the strips above, along the same
+// diagonal) is loaded while the current one is being walked.
+constexpr int kWalkGroups = 5;                        // 32-step groups per strip of the window
+#ifndef PW_WALK_STRIPS
+#define PW_WALK_STRIPS 4
+#endif
+constexpr int kWalkStrips = PW_WALK_STRIPS;           // strips per window
+constexpr int kWalkWinWords = kWalkStrips * kWalkGroups * 64 * 4;   // dwords of LDS
 
 template <class P>
 PW_FN void strip_walk(const StripTraceParams& p, uint32_t* win) {
@@ -683,49 +687,104 @@ PW_FN void strip_walk(const StripTraceParams& p, uint32_t* win) {
   int x = ei, y = ej;
   int pos = p.tx_cap, nms = 0, bad = 0, prev = 3;
   uint8_t* tx = p.tx;
-  int cw = -1, cg = -1;                 // the window: strip cw, groups cg - 3 .. cg
-  int pw = -1, pg = -1;                 // the window being loaded ahead
-  U4 pre[kWalkGroups];
+  // The window: kWalkStrips strips at once -- sub-window s is strip cw - s with its groups cgs[s] - (kWalkGroups - 1) .. cgs[s],
+  // chosen along the diagonal through the cell the window was loaded for (a strip is crossed in at most 64 diagonal moves =
+  // 128 steps; five groups hold that from any entry point).  Round 3: with ONE strip per window the latency of a window's
+  // loads was exposed at every strip crossing -- config 3's 1563 crossings x 2.1 us were its whole 3.35 ms -- although the
+  // next window was already being loaded: a window lasted one or two rounds of the walk.  Now a miss comes every kWalkStrips
+  // strips, the runs of diagonal moves the lanes look along cross strip boundaries, and the NEXT kWalkStrips strips are in
+  // flight meanwhile.  cgs[s] < 0: that strip is not there (above the table, or the chain left it).
+  constexpr int NS = kWalkStrips;
+  int cw = -1, cgs[NS];
+  int pw = -1, pgs[NS];                 // the window being loaded ahead: strips pw - s
+  U4 pre[NS][kWalkGroups];
 #pragma unroll
-  for (int q = 0; q < kWalkGroups; q++) { pre[q].x = pre[q].y = pre[q].z = pre[q].w = 0; }
+  for (int s = 0; s < NS; s++) {
+    cgs[s] = -1; pgs[s] = -1;
+#pragma unroll
+    for (int q = 0; q < kWalkGroups; q++) { pre[s][q].x = pre[s][q].y = pre[s][q].z = pre[s][q].w = 0; }
+  }
+  // the top groups of the NS strips the diagonal through (ex, ey) crosses, starting with the strip of (ex, ey) itself (top group
+  // g0 given) or -- FROM_NEXT -- with the strip above it; returns the cell with which the diagonal leaves the last of them
+  auto chain = [&](int ex, int ey, int w0, bool from_next, int g0, int (&out)[NS], int& lx, int& ly) {
+    int cx_ = ex, cy_ = ey, cwv = w0;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      if (s > 0 || from_next) {
+        const int mi = (cx_ & 63) + 1;                       // diagonal moves to the strip above
+        const bool ok = cwv > 0 && cy_ - mi >= 0 && cx_ >= 0;
+        cx_ = ok ? cx_ - mi : -1; cy_ = ok ? cy_ - mi : -1; cwv = ok ? cwv - 1 : -1;
+        out[s] = ok ? ((cy_ + 63) >> 5) : -1;               // the entry cell sits in row 63 of that strip: k = y + 63
+      } else {
+        out[s] = g0;
+      }
+    }
+    lx = cx_; ly = cy_;
+  };
+  int nx_ = -1, ny_ = -1;               // the cell with which the diagonal leaves the window loaded ahead
   while (true) {
     if (x < 0 || y < 0 || x > p.X || y > p.Y) { bad = 1; break; }
     const int w = x >> 6, i = x & 63, k = y + i, g = k >> 5;
-    if (w != cw || g > cg || g < cg - (kWalkGroups - 1)) {
-      // ---- new window.  Use the one loaded ahead if it holds the cell with at least two groups below it.
-      const bool hit = w == pw && g <= pg && g >= pg - (kWalkGroups - 3);
-      cw = w; cg = hit ? pg : g;
+    const int s0 = cw - w;
+    int cg0 = -1;
+#pragma unroll
+    for (int s = 0; s < NS; s++) cg0 = s0 == s ? cgs[s] : cg0;
+    if (cw < 0 || s0 < 0 || s0 >= NS || cg0 < 0 || g > cg0 || g < cg0 - (kWalkGroups - 1)) {
+      // ---- new window.  Use the one loaded ahead if its first strip holds the cell with at least two groups below it.
+      const bool hit = w == pw && pgs[0] >= 0 && g <= pgs[0] && g >= pgs[0] - (kWalkGroups - 3);
+      int lx = -1, ly = -1;
+      cw = w;
+      if (hit) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) cgs[s] = pgs[s];
+        lx = nx_; ly = ny_;
+      } else {
+        chain(x, y, w, false, g, cgs, lx, ly);
+      }
       P::wave_sync();
 #pragma unroll
-      for (int q = 0; q < kWalkGroups; q++) {
-        U4 v = pre[q];
-        if (!hit) {
-          v.x = v.y = v.z = v.w = 0;
-          if (cg - q >= 0) v = *(const U4*)(p.masks + strip_mask_index(nkq, cw, cg - q, lane));
+      for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int q = 0; q < kWalkGroups; q++) {
+          U4 v = pre[s][q];
+          if (!hit) {
+            v.x = v.y = v.z = v.w = 0;
+            if (cgs[s] >= 0 && cgs[s] - q >= 0) v = *(const U4*)(p.masks + strip_mask_index(nkq, cw - s, cgs[s] - q, lane));
+          }
+          uint32_t* dst = win + ((s * kWalkGroups + q) * 64 + lane) * 4;
+          dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
-        uint32_t* dst = win + (q * 64 + lane) * 4;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
       }
       P::wave_sync();
-      // ---- load ahead: the diagonal through the cell leaves the window at the top of the strip or at the window's
-      //      lowest step, whichever comes first
-      const int i2 = x & 63, k2 = y + i2;
-      const int mi = i2 + 1, mk = ((k2 - 32 * (cg - (kWalkGroups - 1))) >> 1) + 1;
-      if (mi <= mk && cw > 0 && y - mi >= 0) { pw = cw - 1; pg = (y - mi + 63) >> 5; }
-      else { pw = cw; pg = cg - kWalkGroups; }
+      // ---- load ahead: the NS strips above this window, along the same diagonal
+      pw = cw - NS;
+      int dummy = 0;
+      if (pw >= 0 && lx >= 0 && ly >= 0 && cgs[NS - 1] >= 0) chain(lx, ly, cw - (NS - 1), true, dummy, pgs, nx_, ny_);
+      else {
+        pw = -1;
 #pragma unroll
-      for (int q = 0; q < kWalkGroups; q++) {
-        pre[q].x = pre[q].y = pre[q].z = pre[q].w = 0;
-        if (pg - q >= 0) pre[q] = *(const U4*)(p.masks + strip_mask_index(nkq, pw, pg - q, lane));
+        for (int s = 0; s < NS; s++) pgs[s] = -1;
       }
-      if (pg < 0) pw = -1;
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int q = 0; q < kWalkGroups; q++) {
+          pre[s][q].x = pre[s][q].y = pre[s][q].z = pre[s][q].w = 0;
+          if (pw >= 0 && pgs[s] >= 0 && pgs[s] - q >= 0) pre[s][q] = *(const U4*)(p.masks + strip_mask_index(nkq, pw - s, pgs[s] - q, lane));
+        }
+      }
+      continue;                          // (look the cell up again in the new window)
     }
-    // ---- lane j looks at the cell j diagonal moves up from (x, y)
-    const int ij = i - lane, kj = k - 2 * lane;
-    const bool inwin = ij >= 0 && y - lane >= 0 && kj >= 32 * (cg - (kWalkGroups - 1));
+    // ---- lane j looks at the cell j diagonal moves up from (x, y), in whichever strip of the window that is
+    const int xj = x - lane, yj = y - lane;
+    const int sj = cw - (xj >> 6), ij = xj & 63, kj = yj + ij;
+    int cgj = -1;
+#pragma unroll
+    for (int s = 0; s < NS; s++) cgj = sj == s ? cgs[s] : cgj;
+    const bool inwin = xj >= 0 && yj >= 0 && sj >= 0 && sj < NS && cgj >= 0 && (kj >> 5) <= cgj && (kj >> 5) >= cgj - (kWalkGroups - 1);
     uint32_t nibj = 0xfu;
     if (inwin) {
-      const uint32_t word = win[((cg - (kj >> 5)) * 64 + ij) * 4 + ((kj >> 3) & 3)];
+      const uint32_t word = win[((sj * kWalkGroups + (cgj - (kj >> 5))) * 64 + ij) * 4 + ((kj >> 3) & 3)];
       nibj = (word >> (4 * (7 - (kj & 7)))) & 15u;
     }
     const uint64_t pure = P::ballot(inwin && (nibj & 7u) == 0u);
