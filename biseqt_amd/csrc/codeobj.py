@@ -122,8 +122,25 @@ def strip_kernel_violations(obj_path):
             bad.append('%s: spills VGPRs (vgpr_spill_count %s, scratch %s B): spill code may use AGPRs'
                        % (n, k.get('vgpr_spill_count'), k.get('private_segment_fixed_size')))
     for sym, lines in disassembly(obj_path, 'k_fill_strip').items():
-        for ln in lines:
-            ins = re.sub(r'\s+', ' ', ln.split('//')[0]).strip()
+        ins_list = [re.sub(r'\s+', ' ', ln.split('//')[0]).strip() for ln in lines]
+        for ins in ins_list:
             if re.search(r'\ba(\d+|\[)', ins) and not any(p.match(ins) for p in _AGPR_OK):
                 bad.append('%s: unexpected AGPR use: %s' % (sym, ins))
+        # No wait of the COMPILER's for vector memory inside the step code: on this target loads and stores share vmcnt, so such
+        # a wait drains the wavefront's mask / FIFO stores -- once per block if it sits in the steady loop (round 3: a value
+        # loaded at the start of a strip whose first use was in the loop put one there: config 3 17.3 -> 18.9 ms).  The waits
+        # that belong there are the hand-over's (asm: s_waitcnt + v_accvgpr_read) and the polls' (asm: load + s_waitcnt).
+        steps = [i for i, ins in enumerate(ins_list) if ins.startswith('v_max3_i32')]
+        for i, ins in enumerate(ins_list):
+            if not (ins.startswith('s_waitcnt') and 'vmcnt' in ins):
+                continue
+            nxt = ins_list[i + 1] if i + 1 < len(ins_list) else ''
+            prv = ins_list[i - 1] if i > 0 else ''
+            if nxt.startswith('v_accvgpr_read_b32') or prv.startswith('global_load') or prv.startswith('global_atomic'):
+                continue
+            before = sum(1 for j in steps if i - 120 <= j < i)
+            after = sum(1 for j in steps if i < j <= i + 120)
+            if before >= 3 and after >= 3:
+                bad.append('%s: a compiler-inserted "%s" inside the step code (instruction %d): a loaded value is first used '
+                           'there -- make it opaque where it is loaded (P::in_vgpr)' % (sym, ins, i))
     return bad

@@ -57,7 +57,8 @@ hipError_t launch_tx_pack(const PairDesc* pairs, const Result* results, const ui
 // strip pipeline (pw_strip.h / pw_strip.hip): one standard-mode pair wider than a workgroup
 struct StripParams;
 struct StripTraceParams;
-hipError_t launch_strip_fill(const StripParams& a, bool track, bool byte_rows, int nworkers, int lds_bytes, hipStream_t st);
+hipError_t launch_strip_fill(const StripParams& a, bool track, bool byte_rows, const uint32_t* ctl_init, int nworkers, int lds_bytes,
+                             hipStream_t st);
 hipError_t launch_strip_trace(const StripTraceParams& p, hipStream_t st);
 hipError_t launch_xcc_census(uint32_t* d_seen8, hipStream_t st);
 hipError_t launch_table_rowmajor(const void* plane, bool f64, int X, int Y, int pitch, double mul, double* out, hipStream_t st);

@@ -48,7 +48,11 @@ struct StripParams {
                              //   row, high dword the epoch; strip w reads row w - 1
   uint32_t* masks;           // this pair's plane: [nstrips][nkq][64][4] dwords
   StripBest* sbest;          // [nstrips] per-strip end-cell candidates
-  uint32_t* ctl;             // [0 .. 7] work-queue heads, one per XCD queue; [kStripAbort] abort flag (a wait ran out of patience)
+  uint32_t* ctl;             // [0 .. 7] work-queue heads, one per XCD queue; [kStripAbort] abort flag (a wait ran out of patience);
+                             // [kStripRows + o] BROW kernels: row o of the substitution table, byte m = subst[o][m] (match / mismatch
+                             // scoring, or any matrix over at most 4 letters whose entries fit a signed byte: _alnchoice_M,
+                             // _pw_internals.c:217-245).  In memory, not in the kernel arguments: four more scalar registers alive
+                             // through the steady loop cost config 3 9 % (17.3 -> 18.9 ms, A/B of two builds on one box).
   Result* result;            // the pair's record
   int32_t X, Y;
   int32_t nstrips, nkq;      // strips of 64 rows; blocks of 32 steps per strip (steps 0 .. Y + 63)
@@ -56,8 +60,6 @@ struct StripParams {
   uint32_t epoch;            // tag of this solve: granules of earlier solves never match (the buffer is never cleared)
   int32_t brule, endrule;
   int32_t match, mismatch, go, ge;
-  uint32_t rows[4];          // BROW kernels: row o of the substitution table, byte m = subst[o][m] (match / mismatch scoring, or
-                             // any matrix over at most 4 letters whose entries fit a signed byte: _alnchoice_M, _pw_internals.c:217-245)
   int32_t spin_limit;        // polls of one FIFO chunk before giving up
   double score_mul;          // reported score = the kernel's integer value times this (dyadic scaling, pw_types.h)
   // Placement (speed and store flavour only): strips are dealt in RUNS of run_len consecutive strips; run r is worked
@@ -69,6 +71,7 @@ struct StripParams {
   uint64_t* stamps;          // tuning aid (PWLIB_STRIP_TRACE): [nstrips][16]: clock stamps [0..6], placement [7], shader-clock counts [8 + i], or null
 };
 constexpr int kStripAbort = 8;     // index of the abort flag in StripParams::ctl
+constexpr int kStripRows = 12;     // ... of the four byte rows
 
 struct StripTraceParams {
   const uint32_t* masks;
@@ -508,7 +511,9 @@ struct StripFill {
     const int oi = x - 1 < 0 ? 0 : (x - 1 > a.X - 1 ? (a.X > 0 ? a.X - 1 : 0) : x - 1);
     oc = (uint32_t)P::in_vgpr((int32_t)oseq[oi]);      // opaque: a compare known to be 8 bits wide is not folded into a byte select
     rowreg = 0;
-    if (BROW) rowreg = oc == 0 ? a.rows[0] : (oc == 1 ? a.rows[1] : (oc == 2 ? a.rows[2] : a.rows[3]));
+    // (made opaque at once: a loaded value whose first use sits in the steady loop would put the compiler's wait for it --
+    //  s_waitcnt vmcnt(0), a drain of this wavefront's stores -- INTO the loop, once per block: 17.3 -> 18.9 ms)
+    if (BROW) rowreg = (uint32_t)P::in_vgpr((int32_t)P::flag_load(a.ctl + kStripRows + (oc & 3u)));
     w0 = 0; w1 = 0; wpend = 0; wshift = 3u - ((uint32_t)lane & 3u); wfrom = (uint32_t)((lane - 4) & 63);
     kbest = 0; mprev_q = -1; bqv = NEG; ksnap = 0; kY = a.Y + lane;
     Hout = NEG; Uout = NEG; Lo = NEG; Hdiag = NEG; best = NEG; bestY = 0; hlast = NEG;

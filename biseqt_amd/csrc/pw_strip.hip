@@ -181,9 +181,10 @@ __global__ __launch_bounds__(64) void k_trace_strip(const StripTraceParams p) {
   strip_walk<DevPS>(p, win);
 }
 
-hipError_t launch_strip_fill(const StripParams& a, bool track, bool byte_rows, int nworkers, int lds_bytes, hipStream_t st) {
-  // the work queue head and the abort flag start at zero
-  hipError_t e = hipMemsetAsync(a.ctl, 0, 16 * sizeof(uint32_t), st);
+hipError_t launch_strip_fill(const StripParams& a, bool track, bool byte_rows, const uint32_t* ctl_init, int nworkers, int lds_bytes,
+                             hipStream_t st) {
+  // the work queue heads and the abort flag start at zero, the byte rows at their values (16 dwords the caller keeps alive)
+  hipError_t e = hipMemcpyAsync(a.ctl, ctl_init, 16 * sizeof(uint32_t), hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return e;
   const dim3 grid((unsigned)nworkers), block(64);
   if (track && byte_rows) hipLaunchKernelGGL((k_fill_strip<true, true>), grid, block, (size_t)lds_bytes, st, a);

@@ -174,6 +174,7 @@ struct pw_batch {
   std::vector<BkClass> classes;
   std::vector<pw::WaveDesc> waves;      // lane-packed kernel: one per wavefront
   std::vector<int32_t> strips;          // standard-mode pairs wider than a workgroup: the strip pipeline (K2c, pw_strip.h)
+  std::vector<uint32_t> strip_ctl_init;                   // per strip pair: the 16 dwords its control block starts from
   uint64_t* d_fifo = nullptr; size_t fifo_alloc = 0, fifo_bytes = 0;   // FIFO rows of the largest strip pair (pairs run one after another)
   pw::StripBest* d_sbest = nullptr;      // [max strips]
   uint32_t* d_ctl = nullptr;             // [strip pairs][2]: work queue head, abort flag
@@ -723,6 +724,7 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
   static const int workers = std::max(1, env_int("PWLIB_STRIP_WAVES", 1024));
   static const int lds_kb = std::max(0, env_int("PWLIB_STRIP_LDS_KB", 0));
   size_t q = 0;
+  if (b->strip_ctl_init.size() != 16 * b->strips.size()) b->strip_ctl_init.assign(16 * b->strips.size(), 0u);
   for (int32_t k : b->strips) {
     const pw::PairDesc& d = b->descs[k];
     pw::StripParams a;
@@ -756,11 +758,16 @@ int launch_strip_fills(pw_batch* b, hipStream_t st) {
     }
     const bool byte_rows = strip_byte_rows_ok(b);
     if (!byte_rows && !b->simple) return fail("internal: a substitution matrix on the strips needs their byte rows");
+    // (the 16 dwords the control block starts from: zeros and, behind them, the byte rows; kept in the batch until it dies)
+    uint32_t* ci = b->strip_ctl_init.data() + 16 * (q - 1);
+    uint32_t rows[4] = {0u, 0u, 0u, 0u};
     if (byte_rows)
       for (int o = 0; o < 4; o++)
         for (int m = 0; m < 4; m++)
-          if (o < b->L && m < b->L) a.rows[o] |= ((uint32_t)(int32_t)b->subst[(size_t)o * b->L + m] & 0xffu) << (8 * m);
-    HIP_TRY(pw::launch_strip_fill(a, track, byte_rows, workers, lds_kb << 10, st));
+          if (o < b->L && m < b->L) rows[o] |= ((uint32_t)(int32_t)b->subst[(size_t)o * b->L + m] & 0xffu) << (8 * m);
+    // (written once per batch in effect: every solve stores the same values, also while an earlier copy may still be reading them)
+    for (int z = 0; z < 16; z++) ci[z] = (z >= pw::kStripRows && z < pw::kStripRows + 4) ? rows[z - pw::kStripRows] : 0u;
+    HIP_TRY(pw::launch_strip_fill(a, track, byte_rows, ci, workers, lds_kb << 10, st));
     if (d_stamps) {
       std::vector<uint64_t> h((size_t)a.nstrips * 16);
       HIP_TRY(hipStreamSynchronize(st));

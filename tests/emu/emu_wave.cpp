@@ -422,10 +422,10 @@ extern "C" int emu_solve_strip(int type, const int* origin, int X, const int* mu
     brow = true;
     for (int o = 0; o < g_strip_L; o++)
       for (int m = 0; m < g_strip_L; m++)
-        a.rows[o] |= ((uint32_t)(int32_t)g_strip_subst[o * g_strip_L + m] & 0xffu) << (8 * m);
+        ctl[pw::kStripRows + o] |= ((uint32_t)(int32_t)g_strip_subst[o * g_strip_L + m] & 0xffu) << (8 * m);
   } else if (brow) {
     for (int o = 0; o < 4; o++)
-      for (int m = 0; m < 4; m++) a.rows[o] |= ((uint32_t)(o == m ? a.match : a.mismatch) & 0xffu) << (8 * m);
+      for (int m = 0; m < 4; m++) ctl[pw::kStripRows + o] |= ((uint32_t)(o == m ? a.match : a.mismatch) & 0xffu) << (8 * m);
   }
   for (int w = 0; w < a.nstrips; w++) {
     Emu emu;
