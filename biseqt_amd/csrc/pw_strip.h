@@ -51,8 +51,8 @@ struct StripParams {
   uint32_t* ctl;             // [0 .. 7] work-queue heads, one per XCD queue; [kStripAbort] abort flag (a wait ran out of patience);
                              // [kStripRows + o] BROW kernels: row o of the substitution table, byte m = subst[o][m] (match / mismatch
                              // scoring, or any matrix over at most 4 letters whose entries fit a signed byte: _alnchoice_M,
-                             // _pw_internals.c:217-245).  In memory, not in the kernel arguments: four more scalar registers alive
-                             // through the steady loop cost config 3 9 % (17.3 -> 18.9 ms, A/B of two builds on one box).
+                             // _pw_internals.c:217-245).  In memory, not in the kernel arguments: the kernel is short of scalar
+                             // registers as it is (83 spilled), and a lane reads its one row once per strip.
   Result* result;            // the pair's record
   int32_t X, Y;
   int32_t nstrips, nkq;      // strips of 64 rows; blocks of 32 steps per strip (steps 0 .. Y + 63)
