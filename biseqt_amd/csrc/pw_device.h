@@ -40,7 +40,16 @@ PW_FN uint32_t dev_lds_handle(const void* p) {      // the LDS address of a __sh
 }
 
 // Platform policy of the lane program on a CDNA wave64.
+// A dword of a read-only frame (the letter arena) at a WAVE-UNIFORM index: from the constant address space, i.e. a scalar
+// load (lgkmcnt).  A plain load would be a vector one, and on this target vector loads share vmcnt with the stores: the
+// compiler's wait for the load then waits for the mask stores in front of it as well.
+PW_FN uint32_t dev_const_dword(const uint8_t* base, int idx) {
+  typedef const __attribute__((address_space(4))) uint32_t c_u32;
+  return ((c_u32*)base)[idx];
+}
+
 struct DevP {
+  PW_FN static uint32_t const_dword(const uint8_t* base, int idx) { return dev_const_dword(base, idx); }
   template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
   PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   PW_FN static int lane() { return (int)(threadIdx.x & 63u); }
@@ -111,6 +120,7 @@ template <int N, int MAXW> PW_FN void wg_shift_left(int32_t* v, const int32_t* o
 // boundary goes through LDS (one slot per wavefront, written by its edge lane) between two workgroup barriers.
 // Every wavefront runs the same sequence of shifts, so the barriers are reached uniformly.
 struct DevPM {
+  PW_FN static uint32_t const_dword(const uint8_t* base, int idx) { return dev_const_dword(base, idx); }
   template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
   PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   PW_FN static int lane() { return (int)threadIdx.x; }
@@ -220,6 +230,7 @@ __global__ __launch_bounds__(512) void k_fill16_mw(const FillParams<int32_t> a) 
 // kTileGhost lanes are ghost copies of the neighbouring tiles' lanes.
 constexpr int kTileLanes = PW_TILE_LANES, kTileGhost = PW_TILE_GHOST, kTileCentral = kTileLanes - 2 * kTileGhost;
 struct DevPT {
+  PW_FN static uint32_t const_dword(const uint8_t* base, int idx) { return dev_const_dword(base, idx); }
   template <typename T, bool A> PW_FN static T tab_read(const T* tab, uint32_t h, uint32_t off, bool in_lds) { return dev_tab_read<T, A>(tab, h, off, in_lds); }
   PW_FN static uint32_t shl1_in(uint32_t m, bool flag) { return dev_shl1_in(m, flag); }
   // Workgroups are dealt to the 8 XCDs round-robin; neighbouring tiles exchange their state through memory between

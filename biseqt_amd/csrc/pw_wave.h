@@ -1034,6 +1034,14 @@ struct WaveFill16 {
     const uint32_t* o32 = (const uint32_t*)oseq;
     const uint32_t* m32 = (const uint32_t*)mseq;
     const int wo = (xfeed_o + 8 * b) >> 2, wm = (yfeed_m + 8 * b) >> 2;
+    if (!SEG) {
+      // one pair per wavefront (or workgroup): the indices are wave-uniform -- scalar loads, which leave vmcnt to the mask stores
+      fo_n0 = P::const_dword(oseq, pw_clampi(wo, 0, owlast)); fo_n1 = P::const_dword(oseq, pw_clampi(wo + 1, 0, owlast));
+      fo_n2 = P::const_dword(oseq, pw_clampi(wo + 2, 0, owlast));
+      fm_n0 = P::const_dword(mseq, pw_clampi(wm, 0, mwlast)); fm_n1 = P::const_dword(mseq, pw_clampi(wm + 1, 0, mwlast));
+      fm_n2 = P::const_dword(mseq, pw_clampi(wm + 2, 0, mwlast));
+      return;
+    }
     fo_n0 = o32[pw_clampi(wo, 0, owlast)]; fo_n1 = o32[pw_clampi(wo + 1, 0, owlast)]; fo_n2 = o32[pw_clampi(wo + 2, 0, owlast)];
     fm_n0 = m32[pw_clampi(wm, 0, mwlast)]; fm_n1 = m32[pw_clampi(wm + 1, 0, mwlast)]; fm_n2 = m32[pw_clampi(wm + 2, 0, mwlast)];
   }

@@ -76,6 +76,7 @@ struct Emu {
 Emu* Emu::self = nullptr;
 
 struct EmuP {
+  static uint32_t const_dword(const uint8_t* base, int idx) { uint32_t v; memcpy(&v, base + 4 * (size_t)idx, 4); return v; }
   template <typename T, bool A> static T tab_read(const T* tab, uint32_t, uint32_t off, bool) { return *(const T*)((const char*)tab + off); }
   static uint32_t shl1_in(uint32_t m, bool flag) { return (m << 1) | (flag ? 1u : 0u); }
   static int lane() { return Emu::self->cur; }
