@@ -389,11 +389,12 @@ struct WaveFill {
     return (uint32_t)(((((uint64_t)hi) << 32) | (uint64_t)lo) >> (8 * r));
   }
   PW_FN void feed_issue(int b) {
-    const uint32_t* o32 = (const uint32_t*)oseq;
-    const uint32_t* m32 = (const uint32_t*)mseq;
+    // (wave-uniform indices into the read-only letter arena: scalar loads, which leave vmcnt to the mask stores)
     const int wo = (xfeed_o + 8 * b) >> 2, wm = (yfeed_m + 8 * b) >> 2;
-    fo_n0 = o32[pw_clampi(wo, 0, owlast)]; fo_n1 = o32[pw_clampi(wo + 1, 0, owlast)]; fo_n2 = o32[pw_clampi(wo + 2, 0, owlast)];
-    fm_n0 = m32[pw_clampi(wm, 0, mwlast)]; fm_n1 = m32[pw_clampi(wm + 1, 0, mwlast)]; fm_n2 = m32[pw_clampi(wm + 2, 0, mwlast)];
+    fo_n0 = P::const_dword(oseq, pw_clampi(wo, 0, owlast)); fo_n1 = P::const_dword(oseq, pw_clampi(wo + 1, 0, owlast));
+    fo_n2 = P::const_dword(oseq, pw_clampi(wo + 2, 0, owlast));
+    fm_n0 = P::const_dword(mseq, pw_clampi(wm, 0, mwlast)); fm_n1 = P::const_dword(mseq, pw_clampi(wm + 1, 0, mwlast));
+    fm_n2 = P::const_dword(mseq, pw_clampi(wm + 2, 0, mwlast));
   }
   PW_FN void feed_commit(int b) {
     const int ro = (xfeed_o + 8 * b) & 3, rm = (yfeed_m + 8 * b) & 3;
