@@ -66,6 +66,26 @@ def test_strip_checker_reports_foreign_agpr_use(monkeypatch):
         assert len(codeobj.strip_kernel_violations('x.o')) == 1, change
 
 
+def test_strip_checker_reports_a_compiler_wait_inside_the_step_code(monkeypatch):
+    """Round 3: a value loaded at the start of a strip whose first use sat in the steady loop put the compiler's wait for it
+    (s_waitcnt vmcnt(0): a drain of the wavefront's own stores) into the loop -- 9 % of config 3.  The checker must tell such a
+    wait from the hand-over's (asm: wait + v_accvgpr_read) and the polls' (asm: load + wait) and from waits outside the step code."""
+    md = {'void pw::k_fill_strip<%s, %s>(pw::StripParams)' % (t, b): dict(agpr_count=4, vgpr_spill_count=0, private_segment_fixed_size=0)
+          for t in ('true', 'false') for b in ('true', 'false')}
+    monkeypatch.setattr(codeobj, 'kernel_metadata', lambda p: md)
+    step = ['v_add_u32_e32 v1, v2, v3', 'v_max3_i32 v4, v5, v6, v7', 'v_cmp_eq_u32_e32 vcc, v1, v4'] * 6
+    setup = ['s_load_dwordx2 s[0:1], s[2:3], 0x0', 'global_load_ubyte v9, v[10:11], off', 's_waitcnt vmcnt(0)', 'v_mov_b32_e32 v1, v9']
+    handover = ['s_waitcnt vmcnt(1)', 'v_accvgpr_read_b32 v7, a3', 'v_accvgpr_read_b32 v8, a2']
+    poll = ['global_load_dwordx2 v[2:3], v[4:5], off nt', 's_waitcnt vmcnt(0)']
+    good = setup + ['v_mov_b32_e32 v0, 0'] * 200 + step + handover + step + poll + step
+    monkeypatch.setattr(codeobj, 'disassembly', lambda p, s=None: {'k_fill_stripILb1ELb1E': list(good)})
+    assert codeobj.strip_kernel_violations('x.o') == []
+    bad = setup + ['v_mov_b32_e32 v0, 0'] * 200 + step + ['s_waitcnt vmcnt(0)', 'v_perm_b32 v1, v2, v2, v3'] + step
+    monkeypatch.setattr(codeobj, 'disassembly', lambda p, s=None: {'k_fill_stripILb1ELb1E': list(bad)})
+    out = codeobj.strip_kernel_violations('x.o')
+    assert len(out) == 1 and 'compiler-inserted' in out[0], out
+
+
 # (512 VGPRs per SIMD lane, allocated in granules of 8: n wavefronts per SIMD fit when each takes at most this many)
 def _vgpr_ceiling(waves):
     return 512 // waves // 8 * 8
